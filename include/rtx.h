@@ -1,0 +1,266 @@
+/*
+ * rtx.h -- C ABI of the MI355X (gfx950) path-tracing backend for magmast/ray-tracer.
+ *
+ * The reference has no FFI of its own: its only seam is the Rust method
+ *     pub fn render(&self, mesh: &(impl Mesh + Sync)) -> RgbImage          (src/camera.rs:98)
+ * called once from main (src/main.rs:579) with the top-level Bvh (src/main.rs:577).  This header is
+ * what a `-sys` crate for that seam binds: the Rust host walks its World / Bvh / Material / Texture
+ * objects once, writes them into the flat arrays below (structure-of-arrays primitives, tagged
+ * references, a reference-topology BVH) and calls rtx_render(); the bytes that come back are the
+ * RgbImage (row-major, top row first, 3 bytes per pixel).
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in any signature; `void* stream` is a hipStream_t (NULL = default).
+ *  - every pointer inside a *_desc_t is borrowed for the duration of the call that receives it.
+ *  - functions return 0 (RTX_OK) or a negative rtx_status; rtx_last_error() gives the thread-local text.
+ *  - all floating point is IEEE binary32; hit decisions are computed without FMA contraction so that
+ *    they are bit-identical to the reference's un-fused Rust arithmetic.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID = -1,     /* bad argument: null pointer, zero image, empty scene, NaN bounds, bad reference */
+    RTX_ERR_UNSUPPORTED = -2, /* well-formed input that this build does not implement */
+    RTX_ERR_DEVICE = -3,      /* HIP runtime failure (message carries hipGetErrorString) */
+    RTX_ERR_NO_DEVICE = -4    /* no gfx950 device visible: there is no CPU fallback */
+} rtx_status;
+
+/* ---- tagged reference to a hittable: kind in bits [31:28], index in bits [27:0] --------------------- */
+typedef uint32_t rtx_ref_t;
+enum {
+    RTX_REF_NODE = 0,   /* index into bvh_nodes        (mesh.rs:554-625  Bvh)                       */
+    RTX_REF_SPHERE = 1, /* index into the sphere SoA   (mesh.rs:103-188  Sphere)                    */
+    RTX_REF_QUAD = 2,   /* index into the quad SoA     (mesh.rs:190-257  Quad)                      */
+    RTX_REF_TRI = 3,    /* index into the triangle SoA (no counterpart in the reference)            */
+    RTX_REF_OBJECT = 4  /* index into objects          (World / Cube / Translate / RotateY / ConstantMedium) */
+};
+#define RTX_REF(kind, index) ((rtx_ref_t)(((uint32_t)(kind) << 28) | ((uint32_t)(index) & 0x0FFFFFFFu)))
+#define RTX_REF_KIND(r) ((uint32_t)(r) >> 28)
+#define RTX_REF_INDEX(r) ((uint32_t)(r) & 0x0FFFFFFFu)
+#define RTX_MISS 0xFFFFFFFFu
+
+/* One Bvh object of the reference (mesh.rs:554-558): its box and its two children, left first.
+ * bounds = x.start, x.end, y.start, y.end, z.start, z.end -- the reference's padded, origin-including
+ * boxes (mesh.rs:567-569, lib.rs:35-39) so that the strict traversal culls exactly as Bvh::hit does. */
+typedef struct rtx_bvh_node {
+    float bounds[6];
+    rtx_ref_t left, right;
+} rtx_bvh_node_t; /* 32 bytes */
+
+/* Composite hittables. */
+enum {
+    RTX_OBJ_LIST = 0,      /* World / Cube (mesh.rs:54-101, :259-322): linear closest-hit scan of refs[first .. first+count) */
+    RTX_OBJ_TRANSLATE = 1, /* mesh.rs:324-354: child, f[0..3] = offset                               */
+    RTX_OBJ_ROTATE_Y = 2,  /* mesh.rs:356-432: child, f[0] = sin_theta, f[1] = cos_theta              */
+    RTX_OBJ_MEDIUM = 3     /* mesh.rs:627-696: child = boundary, f[0] = density, material = Isotropic, prim_id */
+};
+typedef struct rtx_object {
+    uint32_t kind;
+    rtx_ref_t child; /* TRANSLATE / ROTATE_Y / MEDIUM */
+    uint32_t first;  /* LIST: first index into refs */
+    uint32_t count;  /* LIST: number of refs */
+    float f[3];
+    uint32_t material; /* MEDIUM */
+    uint32_t prim_id;  /* MEDIUM: id reported by hits */
+    uint32_t pad[3];
+} rtx_object_t; /* 48 bytes */
+
+/* ---- materials (material.rs) and textures (texture.rs) ---------------------------------------------- */
+enum {
+    RTX_MAT_LAMBERTIAN = 0,    /* material.rs:53-96                                   */
+    RTX_MAT_METAL = 1,         /* material.rs:98-135    param = roughness             */
+    RTX_MAT_DIELECTRIC = 2,    /* material.rs:137-179   param = refraction_index      */
+    RTX_MAT_DIFFUSE_LIGHT = 3, /* material.rs:181-212                                 */
+    RTX_MAT_ISOTROPIC = 4      /* material.rs:214-246                                 */
+};
+typedef struct rtx_material {
+    uint32_t kind;
+    uint32_t texture; /* index into textures (unused by DIELECTRIC) */
+    float param;
+    uint32_t pad;
+} rtx_material_t; /* 16 bytes */
+
+enum {
+    RTX_TEX_SOLID = 0,   /* texture.rs:14-44    rgb                                                 */
+    RTX_TEX_CHECKER = 1, /* texture.rs:46-81    scale, a = even texture, b = odd texture            */
+    RTX_TEX_IMAGE = 2,   /* texture.rs:83-115   a = index into images                               */
+    RTX_TEX_NOISE = 3    /* texture.rs:117-138  scale, a = index into perlins                       */
+};
+typedef struct rtx_texture {
+    uint32_t kind;
+    float scale;
+    uint32_t a, b;
+    float rgb[3];
+    uint32_t pad;
+} rtx_texture_t; /* 32 bytes */
+
+/* Decoded raster of an ImageTexture (image::DynamicImage, texture.rs:84): RGB8, row-major, top row first. */
+typedef struct rtx_image {
+    const uint8_t* rgb;
+    uint32_t width, height;
+} rtx_image_t;
+
+/* Perlin tables (texture.rs:140-145, N = 256).  The reference draws them from thread_rng at construction
+ * (texture.rs:148-185), so they are inputs here: values = 256 xyz triples, perm_* = 256 entries each. */
+typedef struct rtx_perlin {
+    const float* values;
+    const uint32_t* perm_x;
+    const uint32_t* perm_y;
+    const uint32_t* perm_z;
+} rtx_perlin_t;
+
+/* ---- the flattened scene ------------------------------------------------------------------------------ */
+typedef struct rtx_scene_desc {
+    /* spheres, structure of arrays (mesh.rs:104-110): initial_center, center_delta, radius */
+    uint32_t n_spheres;
+    const float *sph_cx, *sph_cy, *sph_cz;
+    const float *sph_dx, *sph_dy, *sph_dz;
+    const float* sph_radius;
+    const uint32_t* sph_material;
+    const uint32_t* sph_prim_id; /* id reported in rtx_hit_t.prim_id */
+
+    /* quads, structure of arrays (mesh.rs:190-199): translation Q, u, v and the derived normal, d, w that
+     * Quad::new computes (mesh.rs:233-244); quad_f[k] is component k of
+     * { Qx,Qy,Qz, ux,uy,uz, vx,vy,vz, nx,ny,nz, wx,wy,wz, d } */
+    uint32_t n_quads;
+    const float* quad_f[16];
+    const uint32_t* quad_material;
+    const uint32_t* quad_prim_id;
+
+    /* triangles, structure of arrays (build-defined primitive, absent from the reference):
+     * tri_f[k] is component k of { v0x,v0y,v0z, v1x,v1y,v1z, v2x,v2y,v2z } */
+    uint32_t n_tris;
+    const float* tri_f[9];
+    const uint32_t* tri_material;
+    const uint32_t* tri_prim_id;
+
+    /* composites and the reference-topology BVH (Bvh::from, mesh.rs:560-605) */
+    uint32_t n_objects;
+    const rtx_object_t* objects;
+    uint32_t n_refs;
+    const rtx_ref_t* refs;
+    uint32_t n_bvh_nodes;
+    const rtx_bvh_node_t* bvh_nodes;
+    rtx_ref_t root; /* what Camera::render is handed: normally RTX_REF(RTX_REF_NODE, 0) */
+
+    uint32_t n_materials;
+    const rtx_material_t* materials;
+    uint32_t n_textures;
+    const rtx_texture_t* textures;
+    uint32_t n_images;
+    const rtx_image_t* images;
+    uint32_t n_perlins;
+    const rtx_perlin_t* perlins;
+} rtx_scene_desc_t;
+
+/* Camera constants exactly as Camera::new derives them (camera.rs:57-96) plus the config fields the
+ * render loop reads (camera.rs:109-168). */
+typedef struct rtx_camera {
+    uint32_t width, height;
+    uint32_t samples_per_pixel;
+    uint32_t max_depth;
+    float defocus_angle;
+    float center[3];
+    float pixel00_loc[3];
+    float pixel_delta_u[3];
+    float pixel_delta_v[3];
+    float defocus_disk_u[3];
+    float defocus_disk_v[3];
+    float background[3];       /* linear RGB (camera.rs:141) */
+    float pixel_samples_scale; /* 1 / samples_per_pixel (camera.rs:91) */
+} rtx_camera_t;
+
+typedef struct rtx_ray {
+    float o[3];
+    float d[3]; /* not normalised (camera.rs:158) */
+    float time;
+} rtx_ray_t; /* 28 bytes */
+
+/* Hit record = the reference's Hit (mesh.rs:23-30) with the material replaced by ids. */
+typedef struct rtx_hit {
+    uint32_t prim_id; /* RTX_MISS when nothing was hit */
+    float t;          /* Hit::distance, in ray-parameter units */
+    float n[3];       /* Hit::normal, already flipped against the ray (mesh.rs:45) */
+    float uv[2];
+    uint32_t front_face; /* Hit::front_face as the reference stores it: always 1 (mesh.rs:47) */
+    float p[3];          /* Hit::point */
+} rtx_hit_t;             /* 44 bytes */
+
+enum {
+    RTX_TRAVERSAL_FAST = 0,  /* library-built SAH BVH over tight boxes, closest hit with the reference's tie-break */
+    RTX_TRAVERSAL_STRICT = 1 /* walks bvh_nodes exactly as Bvh::hit does (mesh.rs:608-620), same boxes, same order */
+};
+
+typedef struct rtx_trace_opts {
+    float tmin, tmax;   /* the Interval handed to Mesh::hit; Camera::ray_color uses [0.001, +inf) (camera.rs:127) */
+    uint32_t traversal; /* RTX_TRAVERSAL_* */
+    uint64_t seed;      /* feeds ConstantMedium's free-flight draw (mesh.rs:659) */
+} rtx_trace_opts_t;
+
+typedef struct rtx_render_opts {
+    uint64_t seed;
+    uint32_t sample_begin, sample_end; /* sample index range to render; 0,0 = all of 0..samples_per_pixel */
+    uint32_t traversal;                /* RTX_TRAVERSAL_* */
+    uint32_t rr_start_depth;           /* Russian roulette from this bounce on; 0 = off (the reference has none) */
+    uint32_t reserved[4];
+} rtx_render_opts_t;
+
+typedef struct rtx_stats {
+    uint64_t samples;     /* pixel samples rendered by the call */
+    uint64_t rays;        /* ray segments handed to the closest-hit search */
+    double kernel_ms;     /* device time of the path-tracing kernel(s), HIP events on the launch stream */
+    double total_ms;      /* wall time of the call */
+    uint32_t n_launches;  /* launches of the dominant kernel */
+    uint32_t pad;
+} rtx_stats_t;
+
+typedef struct rtx_scene rtx_scene_t; /* device-resident scene */
+
+/* Number of usable gfx950 devices; 0 when none (every compute entry point then fails with RTX_ERR_NO_DEVICE). */
+int rtx_device_count(void);
+/* Thread-local text of the last failure on this thread. */
+const char* rtx_last_error(void);
+
+/* Validate, upload to the current HIP device and build the traversal data.  Replaces the borrow of the
+ * top-level Bvh that Camera::render holds for the duration of a render (camera.rs:98). */
+int rtx_scene_create(const rtx_scene_desc_t* desc, rtx_scene_t** out);
+void rtx_scene_destroy(rtx_scene_t* scene);
+
+/* Closest hit of n rays -- the Mesh::hit contract (mesh.rs:17-21) of the top-level object, used by the
+ * parity gate.  Host buffers. */
+int rtx_trace(const rtx_scene_t* scene, const rtx_ray_t* rays, size_t n, const rtx_trace_opts_t* opts,
+              rtx_hit_t* hits_out);
+/* Same with device-resident rays / hits on `stream`; asynchronous. */
+int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts,
+                     rtx_hit_t* hits_dev, void* stream);
+
+/* Camera::render (camera.rs:98-107): renders the whole frame and returns the RgbImage bytes.
+ * rgb8_out: W*H*3 bytes, caller owned.  accum_out (nullable): 3*W*H f32, the per-pixel SUM of radiance
+ * samples before the 1/spp scale (camera.rs:112-119).  stats nullable.  Host buffers; blocks. */
+int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
+               uint8_t* rgb8_out, float* accum_out, rtx_stats_t* stats);
+
+/* Camera::render_pixel's sample loop (camera.rs:109-122) for the samples [sample_begin, sample_end) of every
+ * pixel: ADDS their radiance sum into accum_dev (3*W*H f32, device memory, caller zeroes it).  This is the
+ * unit that multi-GPU sample splitting shards; the buffers of all ranks are summed before rtx_resolve.
+ * Asynchronous on `stream` unless stats is non-null (then it synchronises the stream to read the timers). */
+int rtx_render_accumulate(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
+                          float* accum_dev, void* stream, rtx_stats_t* stats);
+
+/* camera.rs:101, :119: rgb8 = round(clamp(srgb_oetf(accum * scale), 0, 1) * 255).  Device buffers. */
+int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float scale, uint8_t* rgb8_dev,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */
