@@ -1,0 +1,760 @@
+// librtx.so -- HIP kernels for gfx950 and the C ABI of include/rtx.h.
+//
+// Kernels
+//   trace_kernel    closest hit of arbitrary rays (the Mesh::hit contract); one lane per ray.
+//   render_kernel   Camera::render_pixel / ray_color as a persistent wavefront path tracer (see below).
+//   reduce_kernel   sums the per-batch partial images into the caller's accumulation buffer, in batch order.
+//   resolve_kernel  1/spp scale, sRGB transfer and 8-bit quantisation.
+//
+// render_kernel.  Work is cut into items = (8x8 pixel tile, batch of sample indices).  Each 64-lane wave claims
+// items from a global counter and owns an item's pool of (pixel, sample) pairs: a lane that needs work takes the
+// next pair from the pool (ray generation), walks the threaded BVH held in LDS (extend), and when enough lanes of
+// the wave have finished their walk the wave shades them together (material evaluation, scatter), after which
+// finished paths are replaced from the pool in the same pass, so the wave's lanes stay compacted without any
+// queue in memory.  Radiance is added into the wave's tile accumulator in LDS and written once per item into a
+// per-batch partial image: no global atomics, and the result does not depend on how items were scheduled.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "accel.hpp"
+#include "rtx.h"
+#include "rtx_device.hpp"
+
+using namespace rtxd;
+
+// ================================================================================================ errors
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ================================================================================================ scene
+struct rtx_scene {
+    int device = 0;
+    DevScene dev{};
+    std::vector<void*> allocs;
+    uint32_t n_ents[2] = {0, 0};
+    uint32_t n_boxes[2] = {0, 0};
+    // render scratch (per scene, grown on demand)
+    float* partial = nullptr;
+    size_t partial_bytes = 0;
+    uint32_t* counters = nullptr;  // [0] item counter, [2..3] ray counter (u64)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 0;
+};
+
+template <class T>
+static int upload(rtx_scene* s, const std::vector<T>& host, const T** dev_out) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (!host.empty()) HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = reinterpret_cast<const T*>(p);
+    return RTX_OK;
+}
+
+static bool tex_reads_uv(const rtx_scene_desc_t& d, uint32_t t, int depth = 0) {
+    if (t >= d.n_textures || depth > 16) return false;
+    const rtx_texture_t& x = d.textures[t];
+    if (x.kind == RTX_TEX_IMAGE) return true;
+    if (x.kind == RTX_TEX_CHECKER) return tex_reads_uv(d, x.a, depth + 1) || tex_reads_uv(d, x.b, depth + 1);
+    return false;
+}
+
+extern "C" int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
+
+static int validate(const rtx_scene_desc_t* d) {
+    if (!d) return fail(RTX_ERR_INVALID, "null scene description");
+    if (d->n_spheres && !(d->sph_cx && d->sph_cy && d->sph_cz && d->sph_dx && d->sph_dy && d->sph_dz && d->sph_radius && d->sph_material && d->sph_prim_id))
+        return fail(RTX_ERR_INVALID, "sphere arrays missing");
+    if (d->n_quads) {
+        for (int k = 0; k < 16; k++)
+            if (!d->quad_f[k]) return fail(RTX_ERR_INVALID, "quad arrays missing");
+        if (!d->quad_material || !d->quad_prim_id) return fail(RTX_ERR_INVALID, "quad arrays missing");
+    }
+    if (d->n_tris) {
+        for (int k = 0; k < 9; k++)
+            if (!d->tri_f[k]) return fail(RTX_ERR_INVALID, "triangle arrays missing");
+        if (!d->tri_material || !d->tri_prim_id) return fail(RTX_ERR_INVALID, "triangle arrays missing");
+    }
+    if (d->n_spheres + d->n_quads + d->n_tris == 0) return fail(RTX_ERR_INVALID, "empty scene: no primitives");
+    if (d->n_spheres >= (1u << 28) || d->n_quads >= (1u << 27) || d->n_tris >= (1u << 27)) return fail(RTX_ERR_INVALID, "too many primitives");
+    if (d->n_materials == 0 || !d->materials) return fail(RTX_ERR_INVALID, "no materials");
+    if ((d->n_bvh_nodes && !d->bvh_nodes) || (d->n_objects && !d->objects) || (d->n_refs && !d->refs) || (d->n_textures && !d->textures) ||
+        (d->n_images && !d->images) || (d->n_perlins && !d->perlins))
+        return fail(RTX_ERR_INVALID, "array pointer missing for a non-zero count");
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        if (d->sph_material[i] >= d->n_materials) return fail(RTX_ERR_INVALID, "sphere material out of range");
+        if (!(d->sph_radius[i] >= 0.0f)) return fail(RTX_ERR_INVALID, "Radius cannot be less than 0.");
+    }
+    for (uint32_t i = 0; i < d->n_quads; i++)
+        if (d->quad_material[i] >= d->n_materials) return fail(RTX_ERR_INVALID, "quad material out of range");
+    for (uint32_t i = 0; i < d->n_tris; i++)
+        if (d->tri_material[i] >= d->n_materials) return fail(RTX_ERR_INVALID, "triangle material out of range");
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rtx_material_t& m = d->materials[i];
+        if (m.kind > RTX_MAT_ISOTROPIC) return fail(RTX_ERR_INVALID, "unknown material kind");
+        if (m.kind != RTX_MAT_DIELECTRIC && m.texture >= d->n_textures) return fail(RTX_ERR_INVALID, "material texture out of range");
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rtx_texture_t& t = d->textures[i];
+        if (t.kind > RTX_TEX_NOISE) return fail(RTX_ERR_INVALID, "unknown texture kind");
+        if (t.kind == RTX_TEX_CHECKER && (t.a >= d->n_textures || t.b >= d->n_textures)) return fail(RTX_ERR_INVALID, "checker child out of range");
+        if (t.kind == RTX_TEX_IMAGE && t.a >= d->n_images) return fail(RTX_ERR_INVALID, "image index out of range");
+        if (t.kind == RTX_TEX_NOISE && t.a >= d->n_perlins) return fail(RTX_ERR_INVALID, "perlin index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_images; i++)
+        if (!d->images[i].rgb || !d->images[i].width || !d->images[i].height) return fail(RTX_ERR_INVALID, "empty image");
+    for (uint32_t i = 0; i < d->n_perlins; i++) {
+        const rtx_perlin_t& p = d->perlins[i];
+        if (!p.values || !p.perm_x || !p.perm_y || !p.perm_z) return fail(RTX_ERR_INVALID, "perlin tables missing");
+        for (int k = 0; k < 256; k++)
+            if ((p.perm_x[k] | p.perm_y[k] | p.perm_z[k]) > 255u) return fail(RTX_ERR_INVALID, "perlin permutation entry out of range");
+    }
+    return RTX_OK;
+}
+
+extern "C" void rtx_scene_destroy(rtx_scene_t* s) {
+    if (!s) return;
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(s->device);
+    for (void* p : s->allocs) hipFree(p);
+    if (s->partial) hipFree(s->partial);
+    if (s->counters) hipFree(s->counters);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    hipSetDevice(prev);
+    delete s;
+}
+
+static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
+    rtx_accel::Threaded strict, fast;
+    std::string err;
+    int rc = rtx_accel::build(*d, strict, fast, err);
+    if (rc != RTX_OK) return fail(rc, err);
+
+    HIP_TRY(hipGetDevice(&s->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    s->n_cus = prop.multiProcessorCount;
+
+    const rtx_accel::Threaded* th[2] = {&fast, &strict};
+    for (int m = 0; m < 2; m++) {
+        const rtx_accel::Ent* ep = nullptr;
+        if ((rc = upload(s, th[m]->ents, &ep)) != RTX_OK) return rc;
+        s->dev.ents[m] = reinterpret_cast<const uint4*>(ep);
+        if ((rc = upload(s, th[m]->rank, &s->dev.rank[m])) != RTX_OK) return rc;
+        s->dev.n_ents[m] = s->n_ents[m] = (uint32_t)th[m]->ents.size();
+        s->n_boxes[m] = th[m]->n_boxes;
+    }
+    auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto bf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+
+    std::vector<float4> sph(2 * (size_t)d->n_spheres);
+    std::vector<uint32_t> sph_id(d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+        sph[2 * i] = make_float4(d->sph_cx[i], d->sph_cy[i], d->sph_cz[i], d->sph_radius[i]);
+        sph[2 * i + 1] = make_float4(d->sph_dx[i], d->sph_dy[i], d->sph_dz[i], bf(d->sph_material[i]));
+        sph_id[i] = d->sph_prim_id[i];
+    }
+    if ((rc = upload(s, sph, &s->dev.sph)) != RTX_OK) return rc;
+    if ((rc = upload(s, sph_id, &s->dev.sph_id)) != RTX_OK) return rc;
+
+    // planar records: quads as given; triangles through the same derivation Quad::new applies to (Q, u, v)
+    // (mesh.rs:233-244) with Q = v0, u = v1 - v0, v = v2 - v0.
+    size_t n_planar = (size_t)d->n_quads + d->n_tris;
+    std::vector<float4> planar(5 * n_planar);
+    std::vector<uint32_t> planar_id(n_planar);
+    for (uint32_t i = 0; i < d->n_quads; i++) {
+        const float* const* q = d->quad_f;
+        planar[5 * i + 0] = make_float4(q[0][i], q[1][i], q[2][i], q[15][i]);
+        planar[5 * i + 1] = make_float4(q[3][i], q[4][i], q[5][i], bf(d->quad_material[i]));
+        planar[5 * i + 2] = make_float4(q[6][i], q[7][i], q[8][i], 0.0f);
+        planar[5 * i + 3] = make_float4(q[9][i], q[10][i], q[11][i], 0.0f);
+        planar[5 * i + 4] = make_float4(q[12][i], q[13][i], q[14][i], 0.0f);
+        planar_id[i] = d->quad_prim_id[i];
+    }
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        const float* const* t = d->tri_f;
+        float q[3] = {t[0][i], t[1][i], t[2][i]};
+        float u[3] = {t[3][i] - q[0], t[4][i] - q[1], t[5][i] - q[2]};
+        float v[3] = {t[6][i] - q[0], t[7][i] - q[1], t[8][i] - q[2]};
+        float n[3] = {u[1] * v[2] - v[1] * u[2], u[2] * v[0] - v[2] * u[0], u[0] * v[1] - v[0] * u[1]};
+        float nn = (n[0] * n[0]) + (n[1] * n[1]) + (n[2] * n[2]);
+        float inv = 1.0f / std::sqrt(nn);
+        float nrm[3] = {n[0] * inv, n[1] * inv, n[2] * inv};
+        float dd = (nrm[0] * q[0]) + (nrm[1] * q[1]) + (nrm[2] * q[2]);
+        size_t p = (size_t)d->n_quads + i;
+        planar[5 * p + 0] = make_float4(q[0], q[1], q[2], dd);
+        planar[5 * p + 1] = make_float4(u[0], u[1], u[2], bf(d->tri_material[i]));
+        planar[5 * p + 2] = make_float4(v[0], v[1], v[2], 0.0f);
+        planar[5 * p + 3] = make_float4(nrm[0], nrm[1], nrm[2], 0.0f);
+        planar[5 * p + 4] = make_float4(n[0] / nn, n[1] / nn, n[2] / nn, 0.0f);
+        planar_id[p] = d->tri_prim_id[i];
+    }
+    if ((rc = upload(s, planar, &s->dev.planar)) != RTX_OK) return rc;
+    if ((rc = upload(s, planar_id, &s->dev.planar_id)) != RTX_OK) return rc;
+    s->dev.n_quads = d->n_quads;
+
+    std::vector<uint4> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rtx_material_t& m = d->materials[i];
+        uint32_t flags = (m.kind != RTX_MAT_DIELECTRIC && tex_reads_uv(*d, m.texture)) ? 1u : 0u;
+        mats[i] = make_uint4(m.kind, m.texture, fb(m.param), flags);
+    }
+    if ((rc = upload(s, mats, &s->dev.mats)) != RTX_OK) return rc;
+
+    std::vector<uint4> texs(2 * (size_t)d->n_textures);
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rtx_texture_t& t = d->textures[i];
+        texs[2 * i] = make_uint4(t.kind, fb(t.scale), t.a, t.b);
+        texs[2 * i + 1] = make_uint4(fb(t.rgb[0]), fb(t.rgb[1]), fb(t.rgb[2]), 0);
+    }
+    if ((rc = upload(s, texs, &s->dev.texs)) != RTX_OK) return rc;
+
+    std::vector<DevImage> images(d->n_images);
+    for (uint32_t i = 0; i < d->n_images; i++) {
+        const rtx_image_t& im = d->images[i];
+        std::vector<uint8_t> px(im.rgb, im.rgb + (size_t)im.width * im.height * 3);
+        const uint8_t* dp = nullptr;
+        if ((rc = upload(s, px, &dp)) != RTX_OK) return rc;
+        images[i] = DevImage{dp, im.width, im.height};
+    }
+    if ((rc = upload(s, images, &s->dev.images)) != RTX_OK) return rc;
+
+    std::vector<float> perlin(1536 * (size_t)d->n_perlins);
+    for (uint32_t i = 0; i < d->n_perlins; i++) {
+        const rtx_perlin_t& p = d->perlins[i];
+        float* dst = &perlin[1536 * (size_t)i];
+        std::memcpy(dst, p.values, 768 * sizeof(float));
+        std::memcpy(dst + 768, p.perm_x, 256 * 4);
+        std::memcpy(dst + 1024, p.perm_y, 256 * 4);
+        std::memcpy(dst + 1280, p.perm_z, 256 * 4);
+    }
+    if ((rc = upload(s, perlin, &s->dev.perlin)) != RTX_OK) return rc;
+
+    HIP_TRY(hipMalloc((void**)&s->counters, 64));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    return RTX_OK;
+}
+
+extern "C" int rtx_scene_create(const rtx_scene_desc_t* desc, rtx_scene_t** out) {
+    if (!out) return fail(RTX_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    int rc = validate(desc);
+    if (rc != RTX_OK) return rc;
+    if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_DEVICE, "no gfx950 device visible (there is no CPU fallback)");
+    rtx_scene* s = new rtx_scene();
+    rc = scene_create_impl(desc, s);
+    if (rc != RTX_OK) {
+        std::string keep = g_err;
+        rtx_scene_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    *out = s;
+    return RTX_OK;
+}
+
+// ================================================================================================ trace
+template <bool STRICT>
+__global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
+                                                    rtx_hit_t* __restrict__ hits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
+    const uint4* __restrict__ ents = S.ents[M];
+    const uint32_t* __restrict__ rank = S.rank[M];
+    const uint32_t n_ents = S.n_ents[M];
+    Ray r;
+    r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
+    r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
+    r.time = rays[i].time;
+    const RayConst rc = ray_const(r);
+    Best best;
+    best.t = tmax;
+    best.ent = NO_HIT;
+    uint32_t idx = 0;
+    while (idx < n_ents) {
+        const uint4 ea = ents[2 * idx], eb = ents[2 * idx + 1];
+        idx = walk_step<STRICT>(S, ea, eb, idx, r, rc, tmin, best, rank);
+    }
+    rtx_hit_t out;
+    if (best.ent == NO_HIT) {
+        out.prim_id = RTX_MISS;
+        out.t = 0.0f;
+        out.n[0] = out.n[1] = out.n[2] = 0.0f;
+        out.uv[0] = out.uv[1] = 0.0f;
+        out.front_face = 0;
+        out.p[0] = out.p[1] = out.p[2] = 0.0f;
+    } else {
+        const uint4 ea = ents[2 * best.ent], eb = ents[2 * best.ent + 1];
+        HitRec h = make_hit<true>(S, ea, eb, r, best.t);
+        out.prim_id = h.prim_id;
+        out.t = best.t;
+        out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
+        out.uv[0] = h.u; out.uv[1] = h.v;
+        out.front_face = 1;  // Hit::new stores `front_face: true` unconditionally (mesh.rs:47)
+        out.p[0] = h.px; out.p[1] = h.py; out.p[2] = h.pz;
+    }
+    hits[i] = out;
+}
+
+extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
+                                void* stream) {
+    if (!scene || !opts || (n && (!rays_dev || !hits_dev))) return fail(RTX_ERR_INVALID, "null argument");
+    if (opts->traversal > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    if (n == 0) return RTX_OK;
+    if (n > ((size_t)1 << 39)) return fail(RTX_ERR_INVALID, "too many rays for one call");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    if (opts->traversal == RTX_TRAVERSAL_STRICT)
+        hipLaunchKernelGGL(trace_kernel<true>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+extern "C" int rtx_trace(const rtx_scene_t* scene, const rtx_ray_t* rays, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_out) {
+    if (!scene || !opts || (n && (!rays || !hits_out))) return fail(RTX_ERR_INVALID, "null argument");
+    if (n == 0) return RTX_OK;
+    HIP_TRY(hipSetDevice(scene->device));
+    rtx_ray_t* dr = nullptr;
+    rtx_hit_t* dh = nullptr;
+    HIP_TRY(hipMalloc((void**)&dr, n * sizeof(rtx_ray_t)));
+    hipError_t e = hipMalloc((void**)&dh, n * sizeof(rtx_hit_t));
+    if (e != hipSuccess) {
+        hipFree(dr);
+        return fail(RTX_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    int rc = RTX_OK;
+    e = hipMemcpy(dr, rays, n * sizeof(rtx_ray_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = rtx_trace_device(scene, dr, n, opts, dh, nullptr);
+        if (rc == RTX_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(hits_out, dh, n * sizeof(rtx_hit_t), hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(dr);
+    hipFree(dh);
+    if (rc != RTX_OK) return rc;
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("trace: ") + hipGetErrorString(e));
+    return RTX_OK;
+}
+
+// ================================================================================================ render
+struct RenderParams {
+    DevScene S;
+    rtx_camera_t cam;
+    uint64_t seed;
+    uint32_t sample_begin, sample_end;
+    uint32_t batch;       // samples per item
+    uint32_t n_batches;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_items;
+    uint32_t rr_start;
+    uint32_t shade_threshold;  // shade as soon as this many lanes of a wave wait for it
+    uint32_t* item_counter;
+    unsigned long long* ray_counter;
+    float* partial;       // [n_batches][H][W][3]
+};
+
+constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int ACC_FLOATS = 64 * 3;
+
+enum : uint32_t { ST_IDLE = 0, ST_WALK = 1, ST_SHADE = 2 };
+
+extern __shared__ uint4 smem[];
+
+template <bool STRICT, bool ENTS_IN_LDS>
+__global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
+    constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
+    const DevScene& S = P.S;
+    const uint32_t n_ents = S.n_ents[M];
+    const uint4* __restrict__ gents = S.ents[M];
+    const uint32_t* __restrict__ rank = S.rank[M];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    // LDS: [entries (optional)] [per-wave tile accumulators]
+    uint32_t ent_u4 = ENTS_IN_LDS ? 2u * n_ents : 0u;
+    float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * ACC_FLOATS;
+    if (ENTS_IN_LDS) {
+        for (uint32_t i = threadIdx.x; i < ent_u4; i += blockDim.x) smem[i] = gents[i];
+        __syncthreads();
+    }
+
+    const rtx_camera_t& C = P.cam;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    unsigned long long rays_traced = 0;
+
+    for (;;) {
+        // ---- claim an item for this wave
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(P.item_counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= P.n_items) break;
+        const uint32_t tile = item % n_tiles, batch = item / n_tiles;
+        const uint32_t tx = (tile % P.tiles_x) * TILE, ty = (tile / P.tiles_x) * TILE;
+        const uint32_t vw = min((uint32_t)TILE, C.width - tx), vh = min((uint32_t)TILE, C.height - ty);
+        const uint32_t npix = vw * vh;
+        const uint32_t s0 = P.sample_begin + batch * P.batch;
+        const uint32_t ns = min(P.batch, P.sample_end - s0);
+        const uint32_t pool_total = npix * ns;
+        uint32_t pool_next = 0;  // wave-uniform
+
+        acc[lane] = 0.0f;
+        acc[lane + 64] = 0.0f;
+        acc[lane + 128] = 0.0f;
+
+        // per-lane path state
+        uint32_t state = ST_IDLE;
+        Ray ray{};
+        RayConst rc{};
+        Best best{};
+        uint32_t idx = 0;
+        float br = 0, bg = 0, bb = 0;  // path throughput
+        uint32_t slot = 0, depth_left = 0;
+        Rng rng{};
+
+        for (;;) {
+            // ---- ray generation: idle lanes take the next (pixel, sample) pairs of the pool (camera.rs:147-163)
+            unsigned long long idle = __ballot(state == ST_IDLE);
+            if (idle && pool_next < pool_total) {
+                uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (state == ST_IDLE && my < pool_total) {
+                    slot = my % npix;
+                    uint32_t sample = s0 + my / npix;
+                    uint32_t x = tx + slot % vw, y = ty + slot / vw;
+                    rng = rng_init(P.seed, y * C.width + x, sample);
+                    float ox = rng_f32(rng) - 0.5f;
+                    float oy = rng_f32(rng) - 0.5f;
+                    float fx = (float)x + ox, fy = (float)y + oy;
+                    float sx = (C.pixel00_loc[0] + (fx * C.pixel_delta_u[0])) + (fy * C.pixel_delta_v[0]);
+                    float sy = (C.pixel00_loc[1] + (fx * C.pixel_delta_u[1])) + (fy * C.pixel_delta_v[1]);
+                    float sz = (C.pixel00_loc[2] + (fx * C.pixel_delta_u[2])) + (fy * C.pixel_delta_v[2]);
+                    ray.ox = C.center[0];
+                    ray.oy = C.center[1];
+                    ray.oz = C.center[2];
+                    if (!(C.defocus_angle <= 0.0f)) {
+                        float dxk, dyk;
+                        random_in_unit_disk(rng, dxk, dyk);
+                        ray.ox = (C.center[0] + (dxk * C.defocus_disk_u[0])) + (dyk * C.defocus_disk_v[0]);
+                        ray.oy = (C.center[1] + (dxk * C.defocus_disk_u[1])) + (dyk * C.defocus_disk_v[1]);
+                        ray.oz = (C.center[2] + (dxk * C.defocus_disk_u[2])) + (dyk * C.defocus_disk_v[2]);
+                    }
+                    ray.dx = sx - ray.ox;
+                    ray.dy = sy - ray.oy;
+                    ray.dz = sz - ray.oz;
+                    ray.time = rng_f32(rng);
+                    br = bg = bb = 1.0f;
+                    depth_left = C.max_depth;
+                    if (depth_left == 0) {
+                        state = ST_IDLE;  // ray_color(depth 0) is black before any hit test (camera.rs:125)
+                    } else {
+                        rc = ray_const(ray);
+                        best.t = __builtin_inff();
+                        best.ent = NO_HIT;
+                        idx = 0;
+                        state = ST_WALK;
+                        rays_traced++;
+                    }
+                }
+                pool_next = min(pool_total, pool_next + (uint32_t)__popcll(idle));
+            }
+            unsigned long long walking = __ballot(state == ST_WALK);
+            unsigned long long waiting = __ballot(state == ST_SHADE);
+            if (!walking && !waiting) {
+                if (pool_next >= pool_total) break;
+                continue;  // max_depth == 0: keep draining the pool
+            }
+
+            // ---- extend: walk the threaded BVH until enough lanes wait for shading (or none walks any more)
+            while (walking && (uint32_t)__popcll(waiting) < P.shade_threshold) {
+                if (state == ST_WALK) {
+                    uint4 ea, eb;
+                    if (ENTS_IN_LDS) {
+                        ea = smem[2 * idx];
+                        eb = smem[2 * idx + 1];
+                    } else {
+                        ea = gents[2 * idx];
+                        eb = gents[2 * idx + 1];
+                    }
+                    idx = walk_step<STRICT>(S, ea, eb, idx, ray, rc, 0.001f, best, rank);
+                    if (idx >= n_ents) state = ST_SHADE;
+                }
+                walking = __ballot(state == ST_WALK);
+                waiting = __ballot(state == ST_SHADE);
+            }
+
+            // ---- shade: camera.rs:127-142 for every lane whose walk is complete
+            if (state == ST_SHADE) {
+                state = ST_IDLE;
+                if (best.ent == NO_HIT) {
+                    atomicAdd(&acc[slot * 3 + 0], br * C.background[0]);
+                    atomicAdd(&acc[slot * 3 + 1], bg * C.background[1]);
+                    atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
+                } else {
+                    uint4 ea, eb;
+                    if (ENTS_IN_LDS) {
+                        ea = smem[2 * best.ent];
+                        eb = smem[2 * best.ent + 1];
+                    } else {
+                        ea = gents[2 * best.ent];
+                        eb = gents[2 * best.ent + 1];
+                    }
+                    // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
+                    uint32_t kind = eb.w & 15u;
+                    uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (eb.w >> 4) + 1].w)
+                                                      : __float_as_uint(S.planar[5 * ((eb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
+                    bool want_uv = (S.mats[mat].w & 1u) != 0u;
+                    HitRec h = want_uv ? make_hit<true>(S, ea, eb, ray, best.t) : make_hit<false>(S, ea, eb, ray, best.t);
+                    ScatterOut so = shade(S, ray, h, rng);
+                    if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
+                        atomicAdd(&acc[slot * 3 + 0], br * so.er);
+                        atomicAdd(&acc[slot * 3 + 1], bg * so.eg);
+                        atomicAdd(&acc[slot * 3 + 2], bb * so.eb);
+                    }
+                    if (so.scattered) {
+                        br *= so.ar;
+                        bg *= so.ag;
+                        bb *= so.ab;
+                        depth_left--;
+                        bool alive = depth_left > 0;
+                        if (alive && P.rr_start && (C.max_depth - depth_left) >= P.rr_start) {
+                            // Russian roulette on the largest |throughput| component (albedos may be negative)
+                            float q = fminf(1.0f, fmaxf(fmaxf(fabsf(br), fabsf(bg)), fabsf(bb)));
+                            if (rng_f32(rng) >= q) {
+                                alive = false;
+                            } else {
+                                float iq = 1.0f / q;
+                                br *= iq;
+                                bg *= iq;
+                                bb *= iq;
+                            }
+                        }
+                        if (alive) {
+                            ray = so.ray;
+                            rc = ray_const(ray);
+                            best.t = __builtin_inff();
+                            best.ent = NO_HIT;
+                            idx = 0;
+                            state = ST_WALK;
+                            rays_traced++;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- write the tile's sums into this batch's partial image (each pixel of each batch has one writer)
+        if (lane < npix) {
+            uint32_t x = tx + lane % vw, y = ty + lane / vw;
+            float* dst = P.partial + ((size_t)batch * C.height * C.width + (size_t)y * C.width + x) * 3;
+            dst[0] = acc[lane * 3 + 0];
+            dst[1] = acc[lane * 3 + 1];
+            dst[2] = acc[lane * 3 + 2];
+        }
+    }
+    // one ray-count update per wave
+    for (int off = 32; off > 0; off >>= 1) rays_traced += __shfl_down(rays_traced, off);
+    if (lane == 0 && rays_traced) atomicAdd(P.ray_counter, rays_traced);
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ partial, uint32_t n_batches, size_t n, float* __restrict__ accum) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accum[i];
+    for (uint32_t b = 0; b < n_batches; b++) s += partial[(size_t)b * n + i];
+    accum[i] = s;
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const float* __restrict__ accum, size_t n, float scale, uint8_t* __restrict__ rgb8) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rgb8[i] = srgb_u8(scale * accum[i]);  // pixel_samples_scale * color (camera.rs:119), then camera.rs:101
+}
+
+static int check_camera(const rtx_camera_t* c) {
+    if (!c) return fail(RTX_ERR_INVALID, "null camera");
+    if (c->width == 0 || c->height == 0) return fail(RTX_ERR_INVALID, "zero image size");
+    if ((uint64_t)c->width * c->height > (1ull << 30)) return fail(RTX_ERR_INVALID, "image too large");
+    if (c->samples_per_pixel == 0) return fail(RTX_ERR_INVALID, "samples_per_pixel is zero");
+    return RTX_OK;
+}
+
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
+}
+
+extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camera_t* cam, const rtx_render_opts_t* opts, float* accum_dev, void* stream,
+                                     rtx_stats_t* stats) {
+    rtx_scene* scene = const_cast<rtx_scene*>(scene_c);
+    if (!scene || !opts || !accum_dev) return fail(RTX_ERR_INVALID, "null argument");
+    int rc = check_camera(cam);
+    if (rc != RTX_OK) return rc;
+    if (opts->traversal > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    uint32_t sb = opts->sample_begin, se = opts->sample_end;
+    if (sb == 0 && se == 0) se = cam->samples_per_pixel;
+    if (se < sb) return fail(RTX_ERR_INVALID, "sample_end < sample_begin");
+    auto t_start = std::chrono::steady_clock::now();
+    hipStream_t st = (hipStream_t)stream;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (se == sb) return RTX_OK;
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != scene->device) return fail(RTX_ERR_INVALID, "scene lives on another device than the current one");
+
+    const uint32_t M = opts->traversal;
+    RenderParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.S = scene->dev;
+    P.cam = *cam;
+    P.seed = opts->seed;
+    P.sample_begin = sb;
+    P.sample_end = se;
+    P.tiles_x = (cam->width + TILE - 1) / TILE;
+    P.tiles_y = (cam->height + TILE - 1) / TILE;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t spp = se - sb;
+    // enough items to balance the waves the chip holds (CUs x 32), few enough that an item amortises its setup
+    const uint32_t want_items = (uint32_t)scene->n_cus * 32u * 4u;
+    uint32_t n_batches = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (want_items + n_tiles - 1) / n_tiles));
+    n_batches = std::min<uint32_t>(n_batches, env_u32("RTX_MAX_BATCHES", 64));
+    P.batch = (spp + n_batches - 1) / n_batches;
+    P.n_batches = (spp + P.batch - 1) / P.batch;
+    P.n_items = n_tiles * P.n_batches;
+    P.rr_start = opts->rr_start_depth;
+    P.shade_threshold = std::max<uint32_t>(1u, std::min<uint32_t>(64u, env_u32("RTX_SHADE_THRESHOLD", 24)));
+
+    const size_t npix3 = (size_t)cam->width * cam->height * 3;
+    const size_t need = npix3 * sizeof(float) * P.n_batches;
+    if (scene->partial_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (scene->partial) hipFree(scene->partial);
+        scene->partial = nullptr;
+        scene->partial_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&scene->partial, need));
+        scene->partial_bytes = need;
+    }
+    P.partial = scene->partial;
+    P.item_counter = scene->counters;
+    P.ray_counter = reinterpret_cast<unsigned long long*>(scene->counters + 2);
+    HIP_TRY(hipMemsetAsync(scene->counters, 0, 64, st));
+
+    const size_t ent_bytes = (size_t)scene->n_ents[M] * 32;
+    const size_t acc_bytes = WAVES_PER_BLOCK * ACC_FLOATS * sizeof(float);
+    const bool in_lds = ent_bytes <= env_u32("RTX_LDS_ENTS_MAX", 72 * 1024);
+    const size_t lds = acc_bytes + (in_lds ? ent_bytes : 0);
+    const uint32_t blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", in_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512))) : 8u);
+    dim3 block(64 * WAVES_PER_BLOCK), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+
+    void (*kern)(RenderParams) = nullptr;
+    if (M == RTX_TRAVERSAL_STRICT)
+        kern = in_lds ? render_kernel<true, true> : render_kernel<true, false>;
+    else
+        kern = in_lds ? render_kernel<false, true> : render_kernel<false, false>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+    HIP_TRY(hipEventRecord(scene->ev0, st));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(scene->ev1, st));
+    {
+        dim3 rb(256), rg((unsigned)((npix3 + 255) / 256));
+        hipLaunchKernelGGL(reduce_kernel, rg, rb, 0, st, (const float*)scene->partial, P.n_batches, npix3, accum_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    if (stats) {
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+        unsigned long long nrays = 0;
+        HIP_TRY(hipMemcpy(&nrays, scene->counters + 2, 8, hipMemcpyDeviceToHost));
+        stats->samples = (uint64_t)cam->width * cam->height * spp;
+        stats->rays = nrays;
+        stats->kernel_ms = ms;
+        stats->n_launches = 1;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float scale, uint8_t* rgb8_dev, void* stream) {
+    if (!accum_dev || !rgb8_dev) return fail(RTX_ERR_INVALID, "null argument");
+    if (!width || !height) return fail(RTX_ERR_INVALID, "zero image size");
+    size_t n = (size_t)width * height * 3;
+    dim3 b(256), g((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(resolve_kernel, g, b, 0, (hipStream_t)stream, accum_dev, n, scale, rgb8_dev);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+extern "C" int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, uint8_t* rgb8_out, float* accum_out,
+                          rtx_stats_t* stats) {
+    if (!scene || !opts || !rgb8_out) return fail(RTX_ERR_INVALID, "null argument");
+    int rc = check_camera(cam);
+    if (rc != RTX_OK) return rc;
+    auto t_start = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t n = (size_t)cam->width * cam->height * 3;
+    float* accum = nullptr;
+    uint8_t* rgb = nullptr;
+    HIP_TRY(hipMalloc((void**)&accum, n * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&rgb, n);
+    if (e != hipSuccess) {
+        hipFree(accum);
+        return fail(RTX_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    rtx_render_opts_t o = *opts;
+    if (o.sample_begin == 0 && o.sample_end == 0) o.sample_end = cam->samples_per_pixel;
+    rtx_stats_t local;
+    e = hipMemset(accum, 0, n * sizeof(float));
+    if (e == hipSuccess) {
+        rc = rtx_render_accumulate(scene, cam, &o, accum, nullptr, &local);
+        if (rc == RTX_OK) rc = rtx_resolve(accum, cam->width, cam->height, cam->pixel_samples_scale, rgb, nullptr);
+        if (rc == RTX_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(rgb8_out, rgb, n, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && accum_out) e = hipMemcpy(accum_out, accum, n * sizeof(float), hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(accum);
+    hipFree(rgb);
+    if (rc != RTX_OK) return rc;
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+    if (stats) {
+        *stats = local;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    return RTX_OK;
+}

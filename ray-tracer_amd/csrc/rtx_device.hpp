@@ -1,0 +1,481 @@
+// Device-side arithmetic of the render path: ray / primitive tests, the threaded closest-hit walk, hit records,
+// textures, materials and the random stream.  Everything that decides WHICH primitive is hit and WHERE follows
+// the reference's expressions operation for operation (this translation unit is compiled with
+// -ffp-contract=off and correctly rounded divide / sqrt), so those results are bit-identical to the Rust code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtx.h"
+
+namespace rtxd {
+
+enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3 };
+constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
+constexpr float PI_F = 3.1415926535897932385f;  // utils.rs:4
+
+struct DevImage {
+    const uint8_t* rgb;
+    uint32_t width, height;
+};
+
+struct DevScene {
+    const uint4* ents[2];      // [RTX_TRAVERSAL_FAST], [RTX_TRAVERSAL_STRICT]: 2 x uint4 per entry
+    const uint32_t* rank[2];   // per entry tie-break rank
+    uint32_t n_ents[2];
+    const float4* sph;         // 2 per sphere: (c0.xyz, r) (dc.xyz, material bits)
+    const uint32_t* sph_id;
+    const float4* planar;      // 5 per quad or triangle: (Q.xyz, d) (u.xyz, material bits) (v.xyz, 0) (n.xyz, 0) (w.xyz, 0)
+    const uint32_t* planar_id; // quads first, then triangles
+    uint32_t n_quads;
+    const uint4* mats;         // (kind, texture, param bits, flags)   flags bit0: texture reads uv
+    const uint4* texs;         // 2 per texture: (kind, scale bits, a, b) (r, g, b bits, 0)
+    const DevImage* images;
+    const float* perlin;       // per table set: 768 floats (values) + 3 * 256 uint32 (perm x, y, z)
+};
+
+struct Ray {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float time;
+};
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
+
+// ---------------------------------------------------------------------------------------------- random stream
+// 32-bit PCG (RXS-M-XS output) with a per-stream increment.  The stream is a pure function of
+// (seed, pixel index, sample index); draw k of a stream is the k-th step from that state.
+struct Rng {
+    uint32_t state, inc;
+};
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ Rng rng_init(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    Rng r;
+    uint32_t h = pcg_hash((uint32_t)seed ^ pixel);
+    h = pcg_hash(h + sample * 0x9E3779B9u);
+    r.state = h;
+    r.inc = (pcg_hash(h ^ (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu) << 1) | 1u;
+    return r;
+}
+__device__ __forceinline__ uint32_t rng_u32(Rng& r) {
+    r.state = r.state * 747796405u + r.inc;
+    uint32_t s = r.state;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+// rand 0.8.5 `gen::<f32>()`: the 24 high bits scaled by 2^-24, in [0,1)
+__device__ __forceinline__ float rng_f32(Rng& r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
+
+// Uniform direction on the unit sphere from two draws: the distribution of utils.rs:37-39
+// (normalised rejection sample) without the rejection loop.
+__device__ __forceinline__ void random_unit_vec(Rng& r, float& x, float& y, float& z) {
+    float u1 = rng_f32(r);
+    float u2 = rng_f32(r);
+    z = 1.0f - 2.0f * u1;
+    float rr = __builtin_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    x = rr * __builtin_amdgcn_cosf(u2);  // hardware cos takes revolutions: cos(2*pi*u2)
+    y = rr * __builtin_amdgcn_sinf(u2);
+}
+// Uniform point in the unit disk (utils.rs:28-35 without the rejection loop).
+__device__ __forceinline__ void random_in_unit_disk(Rng& r, float& x, float& y) {
+    float u1 = rng_f32(r);
+    float u2 = rng_f32(r);
+    float rr = __builtin_sqrtf(u1);
+    x = rr * __builtin_amdgcn_cosf(u2);
+    y = rr * __builtin_amdgcn_sinf(u2);
+}
+
+// ---------------------------------------------------------------------------------------------- glam-order helpers
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx) + (ay * by) + (az * bz);
+}
+
+// ---------------------------------------------------------------------------------------------- closest-hit walk
+struct RayConst {  // per-ray values the tests reuse (same expressions the reference re-evaluates per call)
+    float ix, iy, iz;  // 1.0 / direction  (mesh.rs:517)
+    float a;           // direction.length_squared()  (mesh.rs:116)
+};
+__device__ __forceinline__ RayConst ray_const(const Ray& r) {
+    RayConst c;
+    c.ix = 1.0f / r.dx;
+    c.iy = 1.0f / r.dy;
+    c.iz = 1.0f / r.dz;
+    c.a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+    return c;
+}
+
+// Aabb::hit (mesh.rs:512-538).  Checking end <= start once after the three axes is equivalent to the reference's
+// per-axis early return: start only grows and end only shrinks (NaN operands are ignored by max/min).
+__device__ __forceinline__ bool slab_hit(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, float tmax) {
+    float t0 = (as_f(ea.x) - r.ox) * rc.ix, t1 = (as_f(ea.y) - r.ox) * rc.ix;
+    float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+    tmin = fmaxf(tmin, lo);
+    tmax = fminf(tmax, hi);
+    t0 = (as_f(ea.z) - r.oy) * rc.iy;
+    t1 = (as_f(ea.w) - r.oy) * rc.iy;
+    lo = t0 < t1 ? t0 : t1;
+    hi = t0 < t1 ? t1 : t0;
+    tmin = fmaxf(tmin, lo);
+    tmax = fminf(tmax, hi);
+    t0 = (as_f(eb.x) - r.oz) * rc.iz;
+    t1 = (as_f(eb.y) - r.oz) * rc.iz;
+    lo = t0 < t1 ? t0 : t1;
+    hi = t0 < t1 ? t1 : t0;
+    tmin = fmaxf(tmin, lo);
+    tmax = fminf(tmax, hi);
+    return !(tmax <= tmin);
+}
+
+struct Best {
+    float t;       // running interval end = distance of the closest accepted hit so far
+    uint32_t ent;  // entry index of that hit, NO_HIT while none
+};
+
+// Accept a candidate distance under the mode's rule.
+//  strict: Interval::contains (lib.rs:82-84) against the shrinking interval: tmin <= t < best.
+//  fast  : same closest hit, visited in another order: on an exact tie the primitive the reference tests
+//          first (lower rank) wins, as it does there because the later one needs t < tmax.
+template <bool STRICT>
+__device__ __forceinline__ bool in_range(float t, float tmin, const Best& b, uint32_t idx, const uint32_t* __restrict__ rank) {
+    if (STRICT) return tmin <= t && t < b.t;
+    if (!(tmin <= t)) return false;
+    if (t < b.t) return true;
+    return t == b.t && b.ent != NO_HIT && rank[idx] < rank[b.ent];
+}
+
+// Sphere::hit up to the accepted root (mesh.rs:113-133).
+template <bool STRICT>
+__device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, Best& best,
+                                            uint32_t idx, const uint32_t* __restrict__ rank) {
+    float cx = as_f(ea.x) + as_f(ea.w) * r.time;  // center(time) = initial_center + center_delta * time (mesh.rs:178-180)
+    float cy = as_f(ea.y) + as_f(eb.x) * r.time;
+    float cz = as_f(ea.z) + as_f(eb.y) * r.time;
+    float radius = as_f(eb.z);
+    float ocx = cx - r.ox, ocy = cy - r.oy, ocz = cz - r.oz;
+    float h = dot3(r.dx, r.dy, r.dz, ocx, ocy, ocz);
+    float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - radius * radius;
+    float disc = h * h - rc.a * c;
+    if (disc < 0.0f) return;
+    float sqrtd = __builtin_sqrtf(disc);
+    float root = (h - sqrtd) / rc.a;
+    if (STRICT) {
+        if (!in_range<true>(root, tmin, best, idx, rank)) {
+            root = (h + sqrtd) / rc.a;
+            if (!in_range<true>(root, tmin, best, idx, rank)) return;
+        }
+    } else {
+        // the first root inside [tmin, end) is the near one unless it lies before tmin
+        if (!(tmin <= root)) root = (h + sqrtd) / rc.a;
+        if (!in_range<false>(root, tmin, best, idx, rank)) return;
+    }
+    best.t = root;
+    best.ent = idx;
+}
+
+// Quad::hit (mesh.rs:202-221, :248-256); TRI uses the same plane / alpha / beta with the triangle's domain.
+template <bool STRICT>
+__device__ __forceinline__ void planar_test(const float4* __restrict__ planar, uint32_t pidx, bool is_tri, const Ray& r, float tmin, Best& best,
+                                            uint32_t idx, const uint32_t* __restrict__ rank) {
+    const float4 q = planar[5 * pidx], n = planar[5 * pidx + 3];
+    float denom = dot3(n.x, n.y, n.z, r.dx, r.dy, r.dz);
+    if (fabsf(denom) < 1e-8f) return;
+    float t = (q.w - dot3(n.x, n.y, n.z, r.ox, r.oy, r.oz)) / denom;
+    if (!in_range<STRICT>(t, tmin, best, idx, rank)) return;
+    const float4 u = planar[5 * pidx + 1], v = planar[5 * pidx + 2], w = planar[5 * pidx + 4];
+    float px = (r.ox + r.dx * t) - q.x, py = (r.oy + r.dy * t) - q.y, pz = (r.oz + r.dz * t) - q.z;
+    // alpha = w . (p x v), beta = w . (u x p)   with glam's cross
+    float alpha = dot3(w.x, w.y, w.z, py * v.z - v.y * pz, pz * v.x - v.z * px, px * v.y - v.x * py);
+    float beta = dot3(w.x, w.y, w.z, u.y * pz - py * u.z, u.z * px - pz * u.x, u.x * py - px * u.y);
+    bool inside = is_tri ? (alpha >= 0.0f && beta >= 0.0f && alpha + beta <= 1.0f)
+                         : (0.0f <= alpha && alpha < 1.0f && 0.0f <= beta && beta < 1.0f);
+    if (!inside) return;
+    best.t = t;
+    best.ent = idx;
+}
+
+// One step of the walk for the entry (ea, eb) at index idx; returns the next index.
+template <bool STRICT>
+__device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t idx, const Ray& r, const RayConst& rc,
+                                              float tmin, Best& best, const uint32_t* __restrict__ rank) {
+    uint32_t kind = eb.w & 15u;
+    if (kind == ENT_BOX) return slab_hit(ea, eb, r, rc, tmin, best.t) ? idx + 1 : eb.z;
+    if (kind == ENT_SPHERE) {
+        sphere_test<STRICT>(ea, eb, r, rc, tmin, best, idx, rank);
+    } else {
+        uint32_t pi = eb.w >> 4;
+        bool tri = kind == ENT_TRI;
+        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, r, tmin, best, idx, rank);
+    }
+    return idx + 1;
+}
+
+// ---------------------------------------------------------------------------------------------- hit record
+struct HitRec {
+    float px, py, pz;  // Hit::point
+    float nx, ny, nz;  // Hit::normal (flipped against the ray, mesh.rs:45)
+    float u, v;
+    uint32_t mat;
+    uint32_t prim_id;
+};
+
+// Sphere::uv (mesh.rs:182-187) of the outward unit normal
+__device__ __forceinline__ void sphere_uv(float nx, float ny, float nz, float& u, float& v) {
+    float theta = acosf(-ny);
+    float phi = atan2f(-nz, nx) + PI_F;
+    u = phi / (2.0f * PI_F);
+    v = theta / PI_F;
+}
+
+// The rest of Sphere::hit / Quad::hit after the root is accepted, plus Hit::new (mesh.rs:33-51, :135-138, :214-220).
+template <bool WANT_UV>
+__device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, const uint4& eb, const Ray& r, float t) {
+    HitRec h;
+    uint32_t kind = eb.w & 15u, pi = eb.w >> 4;
+    h.px = r.ox + r.dx * t;  // Ray::get_point (lib.rs:27-29)
+    h.py = r.oy + r.dy * t;
+    h.pz = r.oz + r.dz * t;
+    float nx, ny, nz;
+    if (kind == ENT_SPHERE) {
+        float cx = as_f(ea.x) + as_f(ea.w) * r.time;
+        float cy = as_f(ea.y) + as_f(eb.x) * r.time;
+        float cz = as_f(ea.z) + as_f(eb.y) * r.time;
+        float radius = as_f(eb.z);
+        nx = (h.px - cx) / radius;
+        ny = (h.py - cy) / radius;
+        nz = (h.pz - cz) / radius;
+        h.u = 0.0f;
+        h.v = 0.0f;
+        if (WANT_UV) sphere_uv(nx, ny, nz, h.u, h.v);
+        h.mat = __float_as_uint(S.sph[2 * pi + 1].w);
+        h.prim_id = S.sph_id[pi];
+    } else {
+        uint32_t p = kind == ENT_TRI ? pi + S.n_quads : pi;
+        const float4 q = S.planar[5 * p], u = S.planar[5 * p + 1], v = S.planar[5 * p + 2], n = S.planar[5 * p + 3], w = S.planar[5 * p + 4];
+        float dx = h.px - q.x, dy = h.py - q.y, dz = h.pz - q.z;
+        h.u = dot3(w.x, w.y, w.z, dy * v.z - v.y * dz, dz * v.x - v.z * dx, dx * v.y - v.x * dy);
+        h.v = dot3(w.x, w.y, w.z, u.y * dz - dy * u.z, u.z * dx - dz * u.x, u.x * dy - dx * u.y);
+        nx = n.x;
+        ny = n.y;
+        nz = n.z;
+        h.mat = __float_as_uint(u.w);
+        h.prim_id = S.planar_id[p];
+    }
+    bool front = dot3(r.dx, r.dy, r.dz, nx, ny, nz) < 0.0f;  // mesh.rs:40
+    h.nx = front ? nx : -nx;
+    h.ny = front ? ny : -ny;
+    h.nz = front ? nz : -nz;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------- textures
+// Rust `as i32` saturates and maps NaN to 0.
+__device__ __forceinline__ int32_t as_i32_sat(float v) {
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 0x7FFFFFFF;
+    if (v <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)v;
+}
+__device__ __forceinline__ uint32_t as_u32_sat(float v) {
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+__device__ __forceinline__ float clamp01(float v) {  // Interval(0..1).clamp (lib.rs:97-99); NaN stays NaN
+    if (v < 0.0f) v = 0.0f;
+    if (v > 1.0f) v = 1.0f;
+    return v;
+}
+
+// Perlin::noise / perlin_interp / turb (texture.rs:187-243)
+__device__ inline float perlin_noise(const float* __restrict__ tab, float px, float py, float pz) {
+    const uint32_t* perm = reinterpret_cast<const uint32_t*>(tab + 768);
+    float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    float u = px - fx, v = py - fy, w = pz - fz;
+    int32_t i = as_i32_sat(fx), j = as_i32_sat(fy), k = as_i32_sat(fz);
+    float uu = u * u * (3.0f - 2.0f * u);
+    float vv = v * v * (3.0f - 2.0f * v);
+    float ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                uint32_t g = perm[(uint32_t)(i + di) & 255u] ^ perm[256 + ((uint32_t)(j + dj) & 255u)] ^ perm[512 + ((uint32_t)(k + dk) & 255u)];
+                float cx = tab[3 * g], cy = tab[3 * g + 1], cz = tab[3 * g + 2];
+                float fi = (float)di, fj = (float)dj, fk = (float)dk;
+                accum += (fi * uu + (1.0f - fi) * (1.0f - uu)) * (fj * vv + (1.0f - fj) * (1.0f - vv)) * (fk * ww + (1.0f - fk) * (1.0f - ww)) *
+                         dot3(cx, cy, cz, u - fi, v - fj, w - fk);
+            }
+    return accum;
+}
+__device__ inline float perlin_turb(const float* __restrict__ tab, float px, float py, float pz, int depth) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int n = 0; n < depth; n++) {
+        accum += weight * perlin_noise(tab, px, py, pz);
+        px = px * 2.0f;
+        py = py * 2.0f;
+        pz = pz * 2.0f;
+        weight *= 0.5f;
+    }
+    return fabsf(accum);
+}
+
+// Texture::value (texture.rs:34-37, :63-74, :100-114, :132-137)
+__device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float v, float px, float py, float pz, float& r, float& g, float& b) {
+    uint4 t0 = S.texs[2 * tex];
+    for (int guard = 0; guard < 16 && t0.x == RTX_TEX_CHECKER; guard++) {
+        float scale = as_f(t0.y);
+        int32_t x = as_i32_sat(floorf(px * scale));
+        int32_t y = as_i32_sat(floorf(py * scale));
+        int32_t z = as_i32_sat(floorf(pz * scale));
+        int32_t sum = (int32_t)((uint32_t)x + (uint32_t)y + (uint32_t)z);
+        tex = (sum % 2 == 0) ? t0.z : t0.w;
+        t0 = S.texs[2 * tex];
+    }
+    if (t0.x == RTX_TEX_SOLID) {
+        uint4 t1 = S.texs[2 * tex + 1];
+        r = as_f(t1.x);
+        g = as_f(t1.y);
+        b = as_f(t1.z);
+    } else if (t0.x == RTX_TEX_IMAGE) {
+        DevImage im = S.images[t0.z];
+        float uc = clamp01(u);
+        float vc = 1.0f - clamp01(v);
+        uint32_t i = as_u32_sat(uc * ((float)im.width - 1.0f));
+        uint32_t j = as_u32_sat(vc * ((float)im.height - 1.0f));
+        const uint8_t* px8 = im.rgb + ((size_t)j * im.width + i) * 3;
+        const float color_scale = 1.0f / 255.0f;
+        r = (float)px8[0] * color_scale;
+        g = (float)px8[1] * color_scale;
+        b = (float)px8[2] * color_scale;
+    } else if (t0.x == RTX_TEX_NOISE) {
+        const float* tab = S.perlin + (size_t)t0.z * 1536;
+        float s = 1.0f + sinf(as_f(t0.y) * pz + 10.0f * perlin_turb(tab, px, py, pz, 7));
+        r = g = b = (1.0f * 0.5f) * s;
+    } else {
+        r = g = b = 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- materials
+// material.rs:13-17; powi(5) as llvm.powi expands it: x * ((x*x)*(x*x))
+__device__ __forceinline__ float reflectance(float cosine, float ri) {
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 *= r0;
+    float b = 1.0f - cosine;
+    float b2 = b * b;
+    float b4 = b2 * b2;
+    return r0 + (1.0f - r0) * (b * b4);
+}
+
+struct ScatterOut {
+    bool scattered;
+    float ar, ag, ab;  // attenuation
+    float er, eg, eb;  // emitted
+    Ray ray;
+};
+
+// Material::emitted + Material::scatter for the hit (camera.rs:128-130; material.rs:70-96, :104-119, :149-173,
+// :198-206, :231-240).  Random draws come in the order the reference makes them.
+__device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitRec& h, Rng& rng) {
+    ScatterOut o;
+    o.scattered = false;
+    o.ar = o.ag = o.ab = 0.0f;
+    o.er = o.eg = o.eb = 0.0f;
+    const uint4 m = S.mats[h.mat];
+    o.ray.ox = h.px;
+    o.ray.oy = h.py;
+    o.ray.oz = h.pz;
+    o.ray.time = rin.time;
+    o.ray.dx = o.ray.dy = o.ray.dz = 0.0f;
+    if (m.x == RTX_MAT_LAMBERTIAN) {
+        float rx, ry, rz;
+        random_unit_vec(rng, rx, ry, rz);
+        float dx = h.nx + rx, dy = h.ny + ry, dz = h.nz + rz;
+        const float s = 1e-8f;  // near_zero (utils.rs:41-44)
+        if (fabsf(dx) < s && fabsf(dy) < s && fabsf(dz) < s) {
+            dx = h.nx;
+            dy = h.ny;
+            dz = h.nz;
+        }
+        tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+        o.ray.dx = dx;
+        o.ray.dy = dy;
+        o.ray.dz = dz;
+        o.scattered = true;
+    } else if (m.x == RTX_MAT_METAL) {
+        // reflect(ray.direction, normal) on the UN-normalised direction, plus roughness * unit vector (material.rs:107-108)
+        float k = 2.0f * dot3(rin.dx, rin.dy, rin.dz, h.nx, h.ny, h.nz);
+        float rx, ry, rz;
+        random_unit_vec(rng, rx, ry, rz);
+        float rough = as_f(m.z);
+        float dx = (rin.dx - k * h.nx) + (rough * rx);
+        float dy = (rin.dy - k * h.ny) + (rough * ry);
+        float dz = (rin.dz - k * h.nz) + (rough * rz);
+        o.ray.dx = dx;
+        o.ray.dy = dy;
+        o.ray.dz = dz;
+        if (dot3(dx, dy, dz, h.nx, h.ny, h.nz) > 0.0f) {
+            tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+            o.scattered = true;
+        }
+    } else if (m.x == RTX_MAT_DIELECTRIC) {
+        // Hit::front_face is always true (mesh.rs:47) so ri = 1 / refraction_index on entry AND exit (material.rs:151-155)
+        float ri = 1.0f / as_f(m.z);
+        float inv_len = 1.0f / __builtin_sqrtf(dot3(rin.dx, rin.dy, rin.dz, rin.dx, rin.dy, rin.dz));
+        float ux = rin.dx * inv_len, uy = rin.dy * inv_len, uz = rin.dz * inv_len;
+        float cos_theta = -fminf(dot3(ux, uy, uz, h.nx, h.ny, h.nz), 1.0f);
+        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = ri * sin_theta > 1.0f;
+        float dx, dy, dz;
+        if (cannot_refract || reflectance(cos_theta, ri) > rng_f32(rng)) {
+            float k = 2.0f * dot3(ux, uy, uz, h.nx, h.ny, h.nz);
+            dx = ux - k * h.nx;
+            dy = uy - k * h.ny;
+            dz = uz - k * h.nz;
+        } else {  // refract (material.rs:23-28)
+            float ct = -fminf(dot3(ux, uy, uz, h.nx, h.ny, h.nz), 1.0f);
+            float ppx = ri * (ux + ct * h.nx), ppy = ri * (uy + ct * h.ny), ppz = ri * (uz + ct * h.nz);
+            float par = -__builtin_sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
+            dx = ppx + par * h.nx;
+            dy = ppy + par * h.ny;
+            dz = ppz + par * h.nz;
+        }
+        o.ar = o.ag = o.ab = 1.0f;
+        o.ray.dx = dx;
+        o.ray.dy = dy;
+        o.ray.dz = dz;
+        o.scattered = true;
+    } else if (m.x == RTX_MAT_DIFFUSE_LIGHT) {
+        tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.er, o.eg, o.eb);
+    } else if (m.x == RTX_MAT_ISOTROPIC) {
+        random_unit_vec(rng, o.ray.dx, o.ray.dy, o.ray.dz);
+        tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+        o.scattered = true;
+    }
+    return o;
+}
+
+// bevy_color Srgba::gamma_function_inverse + to_u8_array_no_alpha (camera.rs:101)
+__device__ __forceinline__ uint8_t srgb_u8(float value) {
+    float s;
+    if (value <= 0.0f)
+        s = value;
+    else if (value <= 0.0031308f)
+        s = value * 12.92f;
+    else
+        s = (1.055f * powf(value, 1.0f / 2.4f)) - 0.055f;
+    if (s < 0.0f) s = 0.0f;
+    if (s > 1.0f) s = 1.0f;
+    float q = roundf(s * 255.0f);
+    if (!(q == q)) return 0;
+    return (uint8_t)q;
+}
+
+}  // namespace rtxd

@@ -1,0 +1,105 @@
+"""Host layer (C++ constructors + flattener) against the oracle, and the C-ABI surface.  No GPU needed."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+F = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def render():
+    return importlib.import_module("ray-tracer_amd.render")
+
+
+def test_c_abi_exports_every_declared_symbol(render):
+    """Every function include/rtx.h declares is exported by librtx.so (and nothing is called here)."""
+    text = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    declared = set(re.findall(r"\b(rtx_[a-z_]+)\s*\(", text))
+    declared -= {"rtx_status"}
+    lib = render.rtx()
+    assert declared == set(render.RTX_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_header(render):
+    assert C.sizeof(render.BvhNode) == 32 and C.sizeof(render.ObjectRec) == 48
+    assert C.sizeof(render.MaterialRec) == 16 and C.sizeof(render.TextureRec) == 32
+    assert C.sizeof(render.CameraFFI) == 4 * 4 + 4 + 7 * 12 + 4
+
+
+@pytest.mark.parametrize("name", ["bouncing-spheres", "quads", "default", "simple-light", "cornell-box", "final-scene"])
+def test_bvh_topology_and_boxes_match_oracle(render, oracle, scenes, name):
+    """Bvh::from restated twice (host layer, oracle) gives the same leaf order and the same node boxes."""
+    cfg, bvh = scenes.make(name, seed=3)
+    hs = render.Scene(bvh, upload=False)
+    om = oracle.OracleMesh(bvh)
+    assert hs.n_prims == om.n_prims
+    assert np.array_equal(hs.leaf_order(), om.leaf_order())
+    assert np.array_equal(hs.bbox(), om.bbox())
+    if name != "final-scene":  # the oracle dump follows only top-level Bvh chains
+        assert np.array_equal(hs.node_boxes(), om.node_boxes())
+
+
+@pytest.mark.parametrize("name", ["bouncing-spheres", "earth", "quads", "cornell-box", "default"])
+def test_camera_constants_match_oracle(render, oracle, scenes, name):
+    cfg = scenes.CAMERAS[name]()
+    a = render.Camera(cfg).constants()
+    b = oracle.OracleCamera(cfg).constants()
+    for k in b:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+def test_flatten_shares_arc_clones(render, scenes):
+    """checkered-spheres pushes one Arc<Lambertian<Checker>> twice (main.rs:233-240): one material, three textures."""
+    cfg, bvh = scenes.make("checkered-spheres")
+    s = render.Scene(bvh, upload=False)  # keep the scene alive: desc borrows from it
+    d = s.desc
+    assert d.n_spheres == 2 and d.n_materials == 1 and d.n_textures == 3
+    assert d.sph_material[0] == d.sph_material[1] == 0
+    assert d.n_bvh_nodes == 1 and d.root == 0
+
+
+def test_flatten_quad_derived_fields(render, scene):
+    """Quad::new derives normal, d, w (mesh.rs:233-244): Q=(-2,-2,0) u=(4,0,0) v=(0,4,0) -> n=(0,0,1) d=0 w=(0,0,1/16)."""
+    w = scene.World().push(scene.Quad((-2, -2, 0), (4, 0, 0), (0, 4, 0), scene.Lambertian.rgb(.5, .5, .5)))
+    s = render.Scene(scene.Bvh(w), upload=False)
+    d = s.desc
+    assert d.n_quads == 1
+    f = [d.quad_f[k][0] for k in range(16)]
+    assert f[9:12] == [0, 0, 1] and f[12:15] == [0, 0, F(1) / F(16)] and f[15] == 0
+
+
+def test_cube_is_a_list_of_six_quads(render, scene):
+    w = scene.World().push(scene.Cube((0, 0, 0), (1, 2, 3), scene.Lambertian.rgb(.5, .5, .5)))
+    s = render.Scene(scene.Bvh(w), upload=False)
+    d = s.desc
+    assert d.n_quads == 6 and d.n_objects == 1  # the cube's inner World; Bvh::from consumes the outer one
+    assert list(s.leaf_order()) == [0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5]  # one-element Bvh: left == right
+
+
+def test_errors(render, scene):
+    with pytest.raises(ValueError):
+        scene.Sphere.stationary((0, 0, 0), -1.0, scene.Lambertian.rgb(1, 1, 1))
+    with pytest.raises(ValueError):
+        scene.Bvh(scene.World())
+    # the native constructor enforces the same assert (mesh.rs:148)
+    be = importlib.import_module("ray-tracer_amd.capi").Backend(render.host(), "rth")
+    m = be.mat_dielectric(1.5)
+    with pytest.raises(ValueError):
+        be.sphere_stationary((0, 0, 0), -1.0, m, 0)
+
+
+def test_no_gpu_means_loud_failure(render, scenes):
+    """Without a gfx950 device the product path refuses to run (no CPU fallback)."""
+    if render.device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg, bvh = scenes.make("quads")
+    with pytest.raises(render.RtxError) as e:
+        render.Scene(bvh, upload=True)
+    assert e.value.code == render.RTX_ERR_NO_DEVICE
