@@ -53,6 +53,7 @@ struct rtx_scene {
     uint32_t* counters = nullptr;  // [0] item counter, [2..3] ray counter (u64)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 0;
+    bool full_features = false;  // scene uses image or noise textures (uv evaluation, Perlin tables)
 };
 
 template <class T>
@@ -236,6 +237,8 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         texs[2 * i + 1] = make_uint4(fb(t.rgb[0]), fb(t.rgb[1]), fb(t.rgb[2]), 0);
     }
     if ((rc = upload(s, texs, &s->dev.texs)) != RTX_OK) return rc;
+    for (uint32_t i = 0; i < d->n_textures; i++)
+        if (d->textures[i].kind == RTX_TEX_IMAGE || d->textures[i].kind == RTX_TEX_NOISE) s->full_features = true;
 
     std::vector<DevImage> images(d->n_images);
     for (uint32_t i = 0; i < d->n_images; i++) {
@@ -381,7 +384,7 @@ struct RenderParams {
     uint32_t tiles_x, tiles_y;
     uint32_t n_items;
     uint32_t rr_start;
-    uint32_t shade_threshold;  // shade as soon as this many lanes of a wave wait for it
+    uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
     uint32_t* item_counter;
     unsigned long long* ray_counter;
     float* partial;       // [n_batches][H][W][3]
@@ -391,11 +394,17 @@ constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int ACC_FLOATS = 64 * 3;
 
-enum : uint32_t { ST_IDLE = 0, ST_WALK = 1, ST_SHADE = 2 };
+enum : uint32_t { ST_IDLE = 0, ST_BOX = 1, ST_PRIM = 2, ST_SHADE = 3 };
 
 extern __shared__ uint4 smem[];
 
-template <bool STRICT, bool ENTS_IN_LDS>
+// Persistent wavefront path tracer.  Every lane of a wave carries one path and is in one of four queues:
+//   IDLE  (needs a new pixel sample)   BOX  (its next entry is a box)   PRIM  (its next entry is a primitive)
+//   SHADE (its walk is complete).
+// Each pass the wave counts the queues and runs the stage whose queue is fullest -- box tests, primitive tests, or
+// service (shade, scatter, then ray generation for the lanes that became free) -- for exactly the lanes queued for
+// it.  Lanes are never moved: compaction happens in time, by always running the stage most lanes wait for.
+template <bool STRICT, bool ENTS_IN_LDS, bool FULL>
 __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     const DevScene& S = P.S;
@@ -414,7 +423,47 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
 
     const rtx_camera_t& C = P.cam;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     unsigned long long rays_traced = 0;
+
+    // per-lane path state
+    uint32_t state, idx = 0;
+    uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;  // the entry at idx, loaded when the lane arrives there
+    Ray ray{};
+    RayConst rc{};
+    Best best{};
+    float br = 0, bg = 0, bb = 0;  // path throughput
+    uint32_t slot = 0, depth_left = 0;
+    Rng rng{};
+
+#define RTX_LOAD_ENTRY(i, a, b)          \
+    do {                                 \
+        if (ENTS_IN_LDS) {               \
+            a = smem[2 * (i)];           \
+            b = smem[2 * (i) + 1];       \
+        } else {                         \
+            a = gents[2 * (i)];          \
+            b = gents[2 * (i) + 1];      \
+        }                                \
+    } while (0)
+#define RTX_ADVANCE(next)                                              \
+    do {                                                               \
+        idx = (next);                                                  \
+        if (idx >= n_ents) {                                           \
+            state = ST_SHADE;                                          \
+        } else {                                                       \
+            RTX_LOAD_ENTRY(idx, ea, eb);                               \
+            state = ((eb.w & 15u) == ENT_BOX) ? ST_BOX : ST_PRIM;      \
+        }                                                              \
+    } while (0)
+#define RTX_BEGIN_WALK()                 \
+    do {                                 \
+        rc = ray_const(ray);             \
+        best.t = __builtin_inff();       \
+        best.ent = NO_HIT;               \
+        rays_traced++;                   \
+        RTX_ADVANCE(0u);                 \
+    } while (0)
 
     for (;;) {
         // ---- claim an item for this wave
@@ -434,156 +483,147 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
         acc[lane] = 0.0f;
         acc[lane + 64] = 0.0f;
         acc[lane + 128] = 0.0f;
-
-        // per-lane path state
-        uint32_t state = ST_IDLE;
-        Ray ray{};
-        RayConst rc{};
-        Best best{};
-        uint32_t idx = 0;
-        float br = 0, bg = 0, bb = 0;  // path throughput
-        uint32_t slot = 0, depth_left = 0;
-        Rng rng{};
+        state = ST_IDLE;
 
         for (;;) {
-            // ---- ray generation: idle lanes take the next (pixel, sample) pairs of the pool (camera.rs:147-163)
-            unsigned long long idle = __ballot(state == ST_IDLE);
-            if (idle && pool_next < pool_total) {
-                uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (state == ST_IDLE && my < pool_total) {
-                    slot = my % npix;
-                    uint32_t sample = s0 + my / npix;
-                    uint32_t x = tx + slot % vw, y = ty + slot / vw;
-                    rng = rng_init(P.seed, y * C.width + x, sample);
-                    float ox = rng_f32(rng) - 0.5f;
-                    float oy = rng_f32(rng) - 0.5f;
-                    float fx = (float)x + ox, fy = (float)y + oy;
-                    float sx = (C.pixel00_loc[0] + (fx * C.pixel_delta_u[0])) + (fy * C.pixel_delta_v[0]);
-                    float sy = (C.pixel00_loc[1] + (fx * C.pixel_delta_u[1])) + (fy * C.pixel_delta_v[1]);
-                    float sz = (C.pixel00_loc[2] + (fx * C.pixel_delta_u[2])) + (fy * C.pixel_delta_v[2]);
-                    ray.ox = C.center[0];
-                    ray.oy = C.center[1];
-                    ray.oz = C.center[2];
-                    if (!(C.defocus_angle <= 0.0f)) {
-                        float dxk, dyk;
-                        random_in_unit_disk(rng, dxk, dyk);
-                        ray.ox = (C.center[0] + (dxk * C.defocus_disk_u[0])) + (dyk * C.defocus_disk_v[0]);
-                        ray.oy = (C.center[1] + (dxk * C.defocus_disk_u[1])) + (dyk * C.defocus_disk_v[1]);
-                        ray.oz = (C.center[2] + (dxk * C.defocus_disk_u[2])) + (dyk * C.defocus_disk_v[2]);
-                    }
-                    ray.dx = sx - ray.ox;
-                    ray.dy = sy - ray.oy;
-                    ray.dz = sz - ray.oz;
-                    ray.time = rng_f32(rng);
-                    br = bg = bb = 1.0f;
-                    depth_left = C.max_depth;
-                    if (depth_left == 0) {
-                        state = ST_IDLE;  // ray_color(depth 0) is black before any hit test (camera.rs:125)
-                    } else {
-                        rc = ray_const(ray);
-                        best.t = __builtin_inff();
-                        best.ent = NO_HIT;
-                        idx = 0;
-                        state = ST_WALK;
-                        rays_traced++;
-                    }
-                }
-                pool_next = min(pool_total, pool_next + (uint32_t)__popcll(idle));
-            }
-            unsigned long long walking = __ballot(state == ST_WALK);
-            unsigned long long waiting = __ballot(state == ST_SHADE);
-            if (!walking && !waiting) {
-                if (pool_next >= pool_total) break;
-                continue;  // max_depth == 0: keep draining the pool
-            }
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(state == ST_BOX));
+            const uint32_t n_prim = (uint32_t)__popcll(__ballot(state == ST_PRIM));
+            const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == ST_SHADE));
+            const uint32_t n_idle = 64u - n_box - n_prim - n_shade;
+            const uint32_t n_serv = n_shade + min(n_idle, pool_total - pool_next);
+            if (n_box + n_prim + n_serv == 0) break;
 
-            // ---- extend: walk the threaded BVH until enough lanes wait for shading (or none walks any more)
-            while (walking && (uint32_t)__popcll(waiting) < P.shade_threshold) {
-                if (state == ST_WALK) {
-                    uint4 ea, eb;
-                    if (ENTS_IN_LDS) {
-                        ea = smem[2 * idx];
-                        eb = smem[2 * idx + 1];
-                    } else {
-                        ea = gents[2 * idx];
-                        eb = gents[2 * idx + 1];
+            if (n_box >= n_prim && n_box >= n_serv) {
+                // ---- extend, box stage: Aabb::hit for the lanes standing at a box; keep going while boxes stay the
+                //      largest queue (one ballot per step: everything that is not BOX is "the rest")
+                const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
+                uint32_t nb;
+                do {
+                    if (state == ST_BOX) {
+                        const bool hit = slab_hit(ea, eb, ray, rc, tmin, best.t);
+                        const uint32_t next = hit ? idx + 1u : eb.z;
+                        RTX_ADVANCE(next);
                     }
-                    idx = walk_step<STRICT>(S, ea, eb, idx, ray, rc, 0.001f, best, rank);
-                    if (idx >= n_ents) state = ST_SHADE;
+                    nb = (uint32_t)__popcll(__ballot(state == ST_BOX));
+                } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
+            } else if (n_prim >= n_serv) {
+                // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive
+                if (state == ST_PRIM) {
+                    const uint32_t kind = eb.w & 15u;
+                    if (kind == ENT_SPHERE) {
+                        sphere_test<STRICT>(ea, eb, ray, rc, tmin, best, idx, rank);
+                    } else {
+                        const uint32_t pi = eb.w >> 4;
+                        const bool tri = kind == ENT_TRI;
+                        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, tmin, best, idx, rank);
+                    }
+                    RTX_ADVANCE(idx + 1u);
                 }
-                walking = __ballot(state == ST_WALK);
-                waiting = __ballot(state == ST_SHADE);
-            }
-
-            // ---- shade: camera.rs:127-142 for every lane whose walk is complete
-            if (state == ST_SHADE) {
-                state = ST_IDLE;
-                if (best.ent == NO_HIT) {
-                    atomicAdd(&acc[slot * 3 + 0], br * C.background[0]);
-                    atomicAdd(&acc[slot * 3 + 1], bg * C.background[1]);
-                    atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
-                } else {
-                    uint4 ea, eb;
-                    if (ENTS_IN_LDS) {
-                        ea = smem[2 * best.ent];
-                        eb = smem[2 * best.ent + 1];
+            } else {
+                // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
+                if (state == ST_SHADE) {
+                    state = ST_IDLE;
+                    if (best.ent == NO_HIT) {
+                        atomicAdd(&acc[slot * 3 + 0], br * C.background[0]);
+                        atomicAdd(&acc[slot * 3 + 1], bg * C.background[1]);
+                        atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
                     } else {
-                        ea = gents[2 * best.ent];
-                        eb = gents[2 * best.ent + 1];
-                    }
-                    // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
-                    uint32_t kind = eb.w & 15u;
-                    uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (eb.w >> 4) + 1].w)
-                                                      : __float_as_uint(S.planar[5 * ((eb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
-                    bool want_uv = (S.mats[mat].w & 1u) != 0u;
-                    HitRec h = want_uv ? make_hit<true>(S, ea, eb, ray, best.t) : make_hit<false>(S, ea, eb, ray, best.t);
-                    ScatterOut so = shade(S, ray, h, rng);
-                    if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
-                        atomicAdd(&acc[slot * 3 + 0], br * so.er);
-                        atomicAdd(&acc[slot * 3 + 1], bg * so.eg);
-                        atomicAdd(&acc[slot * 3 + 2], bb * so.eb);
-                    }
-                    if (so.scattered) {
-                        br *= so.ar;
-                        bg *= so.ag;
-                        bb *= so.ab;
-                        depth_left--;
-                        bool alive = depth_left > 0;
-                        if (alive && P.rr_start && (C.max_depth - depth_left) >= P.rr_start) {
-                            // Russian roulette on the largest |throughput| component (albedos may be negative)
-                            float q = fminf(1.0f, fmaxf(fmaxf(fabsf(br), fabsf(bg)), fabsf(bb)));
-                            if (rng_f32(rng) >= q) {
-                                alive = false;
-                            } else {
-                                float iq = 1.0f / q;
-                                br *= iq;
-                                bg *= iq;
-                                bb *= iq;
+                        uint4 ha, hb;
+                        RTX_LOAD_ENTRY(best.ent, ha, hb);
+                        HitRec h;
+                        if (FULL) {
+                            // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
+                            const uint32_t kind = hb.w & 15u;
+                            const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
+                                                                    : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
+                            const bool want_uv = (S.mats[mat].w & 1u) != 0u;
+                            h = want_uv ? make_hit<true>(S, ha, hb, ray, best.t) : make_hit<false>(S, ha, hb, ray, best.t);
+                        } else {
+                            h = make_hit<false>(S, ha, hb, ray, best.t);
+                        }
+                        ScatterOut so = shade<FULL>(S, ray, h, rng);
+                        if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
+                            atomicAdd(&acc[slot * 3 + 0], br * so.er);
+                            atomicAdd(&acc[slot * 3 + 1], bg * so.eg);
+                            atomicAdd(&acc[slot * 3 + 2], bb * so.eb);
+                        }
+                        if (so.scattered) {
+                            br *= so.ar;
+                            bg *= so.ag;
+                            bb *= so.ab;
+                            depth_left--;
+                            bool alive = depth_left > 0;
+                            if (alive && P.rr_start && (C.max_depth - depth_left) >= P.rr_start) {
+                                // Russian roulette on the largest |throughput| component (albedos may be negative)
+                                const float q = fminf(1.0f, fmaxf(fmaxf(fabsf(br), fabsf(bg)), fabsf(bb)));
+                                if (rng_f32(rng) >= q) {
+                                    alive = false;
+                                } else {
+                                    const float iq = 1.0f / q;
+                                    br *= iq;
+                                    bg *= iq;
+                                    bb *= iq;
+                                }
+                            }
+                            if (alive) {
+                                ray = so.ray;
+                                RTX_BEGIN_WALK();
                             }
                         }
-                        if (alive) {
-                            ray = so.ray;
-                            rc = ray_const(ray);
-                            best.t = __builtin_inff();
-                            best.ent = NO_HIT;
-                            idx = 0;
-                            state = ST_WALK;
-                            rays_traced++;
-                        }
                     }
+                }
+                // ---- service stage 2, ray generation: free lanes take the next (pixel, sample) pairs of the pool
+                //      (camera.rs:147-163)
+                const unsigned long long idle = __ballot(state == ST_IDLE);
+                if (idle && pool_next < pool_total) {
+                    const uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (state == ST_IDLE && my < pool_total) {
+                        slot = my % npix;
+                        const uint32_t sample = s0 + my / npix;
+                        const uint32_t x = tx + slot % vw, y = ty + slot / vw;
+                        rng = rng_init(P.seed, y * C.width + x, sample);
+                        const float ox = rng_f32(rng) - 0.5f;
+                        const float oy = rng_f32(rng) - 0.5f;
+                        const float fx = (float)x + ox, fy = (float)y + oy;
+                        const float sx = (C.pixel00_loc[0] + (fx * C.pixel_delta_u[0])) + (fy * C.pixel_delta_v[0]);
+                        const float sy = (C.pixel00_loc[1] + (fx * C.pixel_delta_u[1])) + (fy * C.pixel_delta_v[1]);
+                        const float sz = (C.pixel00_loc[2] + (fx * C.pixel_delta_u[2])) + (fy * C.pixel_delta_v[2]);
+                        ray.ox = C.center[0];
+                        ray.oy = C.center[1];
+                        ray.oz = C.center[2];
+                        if (!(C.defocus_angle <= 0.0f)) {
+                            float dxk, dyk;
+                            random_in_unit_disk(rng, dxk, dyk);
+                            ray.ox = (C.center[0] + (dxk * C.defocus_disk_u[0])) + (dyk * C.defocus_disk_v[0]);
+                            ray.oy = (C.center[1] + (dxk * C.defocus_disk_u[1])) + (dyk * C.defocus_disk_v[1]);
+                            ray.oz = (C.center[2] + (dxk * C.defocus_disk_u[2])) + (dyk * C.defocus_disk_v[2]);
+                        }
+                        ray.dx = sx - ray.ox;
+                        ray.dy = sy - ray.oy;
+                        ray.dz = sz - ray.oz;
+                        ray.time = rng_f32(rng);
+                        br = bg = bb = 1.0f;
+                        depth_left = C.max_depth;
+                        // ray_color(depth 0) is black before any hit test (camera.rs:125): the lane stays free
+                        if (depth_left != 0) RTX_BEGIN_WALK();
+                    }
+                    pool_next = min(pool_total, pool_next + (uint32_t)__popcll(idle));
                 }
             }
         }
 
         // ---- write the tile's sums into this batch's partial image (each pixel of each batch has one writer)
         if (lane < npix) {
-            uint32_t x = tx + lane % vw, y = ty + lane / vw;
+            const uint32_t x = tx + lane % vw, y = ty + lane / vw;
             float* dst = P.partial + ((size_t)batch * C.height * C.width + (size_t)y * C.width + x) * 3;
             dst[0] = acc[lane * 3 + 0];
             dst[1] = acc[lane * 3 + 1];
             dst[2] = acc[lane * 3 + 2];
         }
     }
+#undef RTX_LOAD_ENTRY
+#undef RTX_ADVANCE
+#undef RTX_BEGIN_WALK
     // one ray-count update per wave
     for (int off = 32; off > 0; off >>= 1) rays_traced += __shfl_down(rays_traced, off);
     if (lane == 0 && rays_traced) atomicAdd(P.ray_counter, rays_traced);
@@ -654,7 +694,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.n_batches = (spp + P.batch - 1) / P.batch;
     P.n_items = n_tiles * P.n_batches;
     P.rr_start = opts->rr_start_depth;
-    P.shade_threshold = std::max<uint32_t>(1u, std::min<uint32_t>(64u, env_u32("RTX_SHADE_THRESHOLD", 24)));
+    P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 2));
 
     const size_t npix3 = (size_t)cam->width * cam->height * 3;
     const size_t need = npix3 * sizeof(float) * P.n_batches;
@@ -679,10 +719,14 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     dim3 block(64 * WAVES_PER_BLOCK), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
 
     void (*kern)(RenderParams) = nullptr;
-    if (M == RTX_TRAVERSAL_STRICT)
-        kern = in_lds ? render_kernel<true, true> : render_kernel<true, false>;
-    else
-        kern = in_lds ? render_kernel<false, true> : render_kernel<false, false>;
+    const bool full = scene->full_features;
+    if (M == RTX_TRAVERSAL_STRICT) {
+        if (full) kern = in_lds ? render_kernel<true, true, true> : render_kernel<true, false, true>;
+        else kern = in_lds ? render_kernel<true, true, false> : render_kernel<true, false, false>;
+    } else {
+        if (full) kern = in_lds ? render_kernel<false, true, true> : render_kernel<false, false, true>;
+        else kern = in_lds ? render_kernel<false, true, false> : render_kernel<false, false, false>;
+    }
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     HIP_TRY(hipEventRecord(scene->ev0, st));

@@ -327,6 +327,7 @@ __device__ inline float perlin_turb(const float* __restrict__ tab, float px, flo
 }
 
 // Texture::value (texture.rs:34-37, :63-74, :100-114, :132-137)
+template <bool FULL>
 __device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float v, float px, float py, float pz, float& r, float& g, float& b) {
     uint4 t0 = S.texs[2 * tex];
     for (int guard = 0; guard < 16 && t0.x == RTX_TEX_CHECKER; guard++) {
@@ -343,7 +344,7 @@ __device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float
         r = as_f(t1.x);
         g = as_f(t1.y);
         b = as_f(t1.z);
-    } else if (t0.x == RTX_TEX_IMAGE) {
+    } else if (FULL && t0.x == RTX_TEX_IMAGE) {
         DevImage im = S.images[t0.z];
         float uc = clamp01(u);
         float vc = 1.0f - clamp01(v);
@@ -354,7 +355,7 @@ __device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float
         r = (float)px8[0] * color_scale;
         g = (float)px8[1] * color_scale;
         b = (float)px8[2] * color_scale;
-    } else if (t0.x == RTX_TEX_NOISE) {
+    } else if (FULL && t0.x == RTX_TEX_NOISE) {
         const float* tab = S.perlin + (size_t)t0.z * 1536;
         float s = 1.0f + sinf(as_f(t0.y) * pz + 10.0f * perlin_turb(tab, px, py, pz, 7));
         r = g = b = (1.0f * 0.5f) * s;
@@ -383,6 +384,7 @@ struct ScatterOut {
 
 // Material::emitted + Material::scatter for the hit (camera.rs:128-130; material.rs:70-96, :104-119, :149-173,
 // :198-206, :231-240).  Random draws come in the order the reference makes them.
+template <bool FULL>
 __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitRec& h, Rng& rng) {
     ScatterOut o;
     o.scattered = false;
@@ -404,7 +406,7 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
             dy = h.ny;
             dz = h.nz;
         }
-        tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+        tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
         o.ray.dx = dx;
         o.ray.dy = dy;
         o.ray.dz = dz;
@@ -422,7 +424,7 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
         o.ray.dy = dy;
         o.ray.dz = dz;
         if (dot3(dx, dy, dz, h.nx, h.ny, h.nz) > 0.0f) {
-            tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+            tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
             o.scattered = true;
         }
     } else if (m.x == RTX_MAT_DIELECTRIC) {
@@ -453,10 +455,10 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
         o.ray.dz = dz;
         o.scattered = true;
     } else if (m.x == RTX_MAT_DIFFUSE_LIGHT) {
-        tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.er, o.eg, o.eb);
+        tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.er, o.eg, o.eb);
     } else if (m.x == RTX_MAT_ISOTROPIC) {
         random_unit_vec(rng, o.ray.dx, o.ray.dy, o.ray.dz);
-        tex_value(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+        tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
         o.scattered = true;
     }
     return o;
