@@ -25,6 +25,11 @@
 namespace rtx_accel {
 
 enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3 };
+// word 7 of an entry doubles as the walk state of a lane standing at it:
+//   0                      a box            (words 0-5 bounds, word 6 = byte offset of the entry to jump to on a miss)
+//   (index << 4) | kind    a primitive      (kind 1..3)
+//   ENT_END                the terminator appended after the last entry: the walk is complete
+constexpr uint32_t ENT_END = 0xFFFFFFFEu;
 
 struct Ent {
     uint32_t w[8];
@@ -289,6 +294,17 @@ struct FastBuilder {
     }
 };
 
+// Turn entry indices into byte offsets and append the terminator.
+static inline void finalize(Threaded& t) {
+    for (Ent& e : t.ents)
+        if (e.w[7] == ENT_BOX) e.w[6] *= (uint32_t)sizeof(Ent);
+    Ent end;
+    std::memset(&end, 0, sizeof(end));
+    end.w[7] = ENT_END;
+    t.ents.push_back(end);
+    t.rank.push_back(0);
+}
+
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.
 static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, std::string& err) {
     StrictBuilder sb(d, strict);
@@ -311,6 +327,9 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     std::sort(prims.begin(), prims.end(), [](const PrimBox& x, const PrimBox& y) { return x.rank < y.rank; });
     FastBuilder fb(prims, d, fast);
     fb.build(0, (uint32_t)prims.size());
+    if (strict.ents.size() >= (1u << 26) || fast.ents.size() >= (1u << 26)) { err = "scene too large for 32-bit entry offsets"; return RTX_ERR_INVALID; }
+    finalize(strict);
+    finalize(fast);
     return RTX_OK;
 }
 

@@ -170,7 +170,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         if ((rc = upload(s, th[m]->ents, &ep)) != RTX_OK) return rc;
         s->dev.ents[m] = reinterpret_cast<const uint4*>(ep);
         if ((rc = upload(s, th[m]->rank, &s->dev.rank[m])) != RTX_OK) return rc;
-        s->dev.n_ents[m] = s->n_ents[m] = (uint32_t)th[m]->ents.size();
+        s->dev.n_ents[m] = s->n_ents[m] = (uint32_t)th[m]->ents.size();  // terminator included
         s->n_boxes[m] = th[m]->n_boxes;
     }
     auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     const uint4* __restrict__ ents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
-    const uint32_t n_ents = S.n_ents[M];
     Ray r;
     r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
     r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
@@ -303,10 +302,11 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
     Best best;
     best.t = tmax;
     best.ent = NO_HIT;
-    uint32_t idx = 0;
-    while (idx < n_ents) {
-        const uint4 ea = ents[2 * idx], eb = ents[2 * idx + 1];
-        idx = walk_step<STRICT>(S, ea, eb, idx, r, rc, tmin, best, rank);
+    uint32_t off = 0;
+    for (;;) {
+        const uint4 ea = ents[off / 16], eb = ents[off / 16 + 1];
+        if (eb.w == ENT_END) break;
+        off = walk_step<STRICT>(S, ea, eb, off, r, rc, tmin, best, rank);
     }
     rtx_hit_t out;
     if (best.ent == NO_HIT) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
         out.front_face = 0;
         out.p[0] = out.p[1] = out.p[2] = 0.0f;
     } else {
-        const uint4 ea = ents[2 * best.ent], eb = ents[2 * best.ent + 1];
+        const uint4 ea = ents[best.ent / 16], eb = ents[best.ent / 16 + 1];
         HitRec h = make_hit<true>(S, ea, eb, r, best.t);
         out.prim_id = h.prim_id;
         out.t = best.t;
@@ -391,30 +391,30 @@ struct RenderParams {
 };
 
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WAVES_PER_BLOCK = 8;  // all waves of a block share one LDS copy of the entries
+constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
 constexpr int ACC_FLOATS = 64 * 3;
-
-enum : uint32_t { ST_IDLE = 0, ST_BOX = 1, ST_PRIM = 2, ST_SHADE = 3 };
 
 extern __shared__ uint4 smem[];
 
-// Persistent wavefront path tracer.  Every lane of a wave carries one path and is in one of four queues:
+// Persistent wavefront path tracer.  Every lane of a wave carries one path and stands in one of four queues:
 //   IDLE  (needs a new pixel sample)   BOX  (its next entry is a box)   PRIM  (its next entry is a primitive)
-//   SHADE (its walk is complete).
-// Each pass the wave counts the queues and runs the stage whose queue is fullest -- box tests, primitive tests, or
-// service (shade, scatter, then ray generation for the lanes that became free) -- for exactly the lanes queued for
-// it.  Lanes are never moved: compaction happens in time, by always running the stage most lanes wait for.
+//   DONE  (its walk is complete and waits for shading).
+// The queue a lane is in is word 7 of the entry it stands at (0 = box, ENT_END = done, ST_IDLE, else primitive), so
+// arriving at an entry also files the lane.  Each pass the wave counts the queues and runs the stage whose queue is
+// fullest -- box tests, primitive tests, or service (shade + scatter, then ray generation for the lanes that became
+// free) -- for exactly the lanes queued for it.  Lanes are never moved: compaction happens in time, by always running
+// the stage most lanes wait for.
 template <bool STRICT, bool ENTS_IN_LDS, bool FULL>
-__global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     const DevScene& S = P.S;
-    const uint32_t n_ents = S.n_ents[M];
     const uint4* __restrict__ gents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
-    // LDS: [entries (optional)] [per-wave tile accumulators]
-    uint32_t ent_u4 = ENTS_IN_LDS ? 2u * n_ents : 0u;
+    // LDS: [entries incl. terminator (optional)] [per-wave tile accumulators]
+    const uint32_t ent_u4 = ENTS_IN_LDS ? 2u * S.n_ents[M] : 0u;
     float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * ACC_FLOATS;
     if (ENTS_IN_LDS) {
         for (uint32_t i = threadIdx.x; i < ent_u4; i += blockDim.x) smem[i] = gents[i];
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
     unsigned long long rays_traced = 0;
 
     // per-lane path state
-    uint32_t state, idx = 0;
-    uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;  // the entry at idx, loaded when the lane arrives there
+    uint32_t off = 0;                            // byte offset of the entry the lane stands at
+    uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;  // that entry; eb.w is the lane's queue
     Ray ray{};
     RayConst rc{};
     Best best{};
@@ -436,25 +436,17 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
     uint32_t slot = 0, depth_left = 0;
     Rng rng{};
 
-#define RTX_LOAD_ENTRY(i, a, b)          \
-    do {                                 \
-        if (ENTS_IN_LDS) {               \
-            a = smem[2 * (i)];           \
-            b = smem[2 * (i) + 1];       \
-        } else {                         \
-            a = gents[2 * (i)];          \
-            b = gents[2 * (i) + 1];      \
-        }                                \
-    } while (0)
-#define RTX_ADVANCE(next)                                              \
-    do {                                                               \
-        idx = (next);                                                  \
-        if (idx >= n_ents) {                                           \
-            state = ST_SHADE;                                          \
-        } else {                                                       \
-            RTX_LOAD_ENTRY(idx, ea, eb);                               \
-            state = ((eb.w & 15u) == ENT_BOX) ? ST_BOX : ST_PRIM;      \
-        }                                                              \
+#define RTX_LOAD_ENTRY(o, a, b)                                                \
+    do {                                                                       \
+        if (ENTS_IN_LDS) {                                                     \
+            const char* base_ = reinterpret_cast<const char*>(smem) + (o);     \
+            a = *reinterpret_cast<const uint4*>(base_);                        \
+            b = *reinterpret_cast<const uint4*>(base_ + 16);                   \
+        } else {                                                               \
+            const char* base_ = reinterpret_cast<const char*>(gents) + (o);    \
+            a = *reinterpret_cast<const uint4*>(base_);                        \
+            b = *reinterpret_cast<const uint4*>(base_ + 16);                   \
+        }                                                                      \
     } while (0)
 #define RTX_BEGIN_WALK()                 \
     do {                                 \
@@ -462,7 +454,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
         best.t = __builtin_inff();       \
         best.ent = NO_HIT;               \
         rays_traced++;                   \
-        RTX_ADVANCE(0u);                 \
+        off = 0;                         \
+        RTX_LOAD_ENTRY(off, ea, eb);     \
     } while (0)
 
     for (;;) {
@@ -483,14 +476,14 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
         acc[lane] = 0.0f;
         acc[lane + 64] = 0.0f;
         acc[lane + 128] = 0.0f;
-        state = ST_IDLE;
+        eb.w = ST_IDLE;
 
         for (;;) {
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(state == ST_BOX));
-            const uint32_t n_prim = (uint32_t)__popcll(__ballot(state == ST_PRIM));
-            const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == ST_SHADE));
-            const uint32_t n_idle = 64u - n_box - n_prim - n_shade;
-            const uint32_t n_serv = n_shade + min(n_idle, pool_total - pool_next);
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
+            const uint32_t n_done = (uint32_t)__popcll(__ballot(eb.w == ENT_END));
+            const uint32_t n_idle = (uint32_t)__popcll(__ballot(eb.w == ST_IDLE));
+            const uint32_t n_prim = 64u - n_box - n_done - n_idle;
+            const uint32_t n_serv = n_done + min(n_idle, pool_total - pool_next);
             if (n_box + n_prim + n_serv == 0) break;
 
             if (n_box >= n_prim && n_box >= n_serv) {
@@ -499,30 +492,31 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
                 uint32_t nb;
                 do {
-                    if (state == ST_BOX) {
-                        const bool hit = slab_hit(ea, eb, ray, rc, tmin, best.t);
-                        const uint32_t next = hit ? idx + 1u : eb.z;
-                        RTX_ADVANCE(next);
+                    if (eb.w == ENT_BOX) {
+                        const bool hit = slab_hit<STRICT>(ea, eb, ray, rc, tmin, best.t);
+                        off = hit ? off + ENT_BYTES : eb.z;
+                        RTX_LOAD_ENTRY(off, ea, eb);
                     }
-                    nb = (uint32_t)__popcll(__ballot(state == ST_BOX));
+                    nb = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
                 } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
             } else if (n_prim >= n_serv) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive
-                if (state == ST_PRIM) {
+                if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
                     const uint32_t kind = eb.w & 15u;
                     if (kind == ENT_SPHERE) {
-                        sphere_test<STRICT>(ea, eb, ray, rc, tmin, best, idx, rank);
+                        sphere_test<STRICT>(ea, eb, ray, rc, tmin, best, off, rank);
                     } else {
                         const uint32_t pi = eb.w >> 4;
                         const bool tri = kind == ENT_TRI;
-                        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, tmin, best, idx, rank);
+                        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, tmin, best, off, rank);
                     }
-                    RTX_ADVANCE(idx + 1u);
+                    off += ENT_BYTES;
+                    RTX_LOAD_ENTRY(off, ea, eb);
                 }
             } else {
                 // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
-                if (state == ST_SHADE) {
-                    state = ST_IDLE;
+                if (eb.w == ENT_END) {
+                    eb.w = ST_IDLE;
                     if (best.ent == NO_HIT) {
                         atomicAdd(&acc[slot * 3 + 0], br * C.background[0]);
                         atomicAdd(&acc[slot * 3 + 1], bg * C.background[1]);
@@ -574,10 +568,10 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
                 }
                 // ---- service stage 2, ray generation: free lanes take the next (pixel, sample) pairs of the pool
                 //      (camera.rs:147-163)
-                const unsigned long long idle = __ballot(state == ST_IDLE);
+                const unsigned long long idle = __ballot(eb.w == ST_IDLE);
                 if (idle && pool_next < pool_total) {
                     const uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    if (state == ST_IDLE && my < pool_total) {
+                    if (eb.w == ST_IDLE && my < pool_total) {
                         slot = my % npix;
                         const uint32_t sample = s0 + my / npix;
                         const uint32_t x = tx + slot % vw, y = ty + slot / vw;
@@ -622,10 +616,9 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
         }
     }
 #undef RTX_LOAD_ENTRY
-#undef RTX_ADVANCE
 #undef RTX_BEGIN_WALK
     // one ray-count update per wave
-    for (int off = 32; off > 0; off >>= 1) rays_traced += __shfl_down(rays_traced, off);
+    for (int o = 32; o > 0; o >>= 1) rays_traced += __shfl_down(rays_traced, o);
     if (lane == 0 && rays_traced) atomicAdd(P.ray_counter, rays_traced);
 }
 
@@ -715,7 +708,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     const size_t acc_bytes = WAVES_PER_BLOCK * ACC_FLOATS * sizeof(float);
     const bool in_lds = ent_bytes <= env_u32("RTX_LDS_ENTS_MAX", 72 * 1024);
     const size_t lds = acc_bytes + (in_lds ? ent_bytes : 0);
-    const uint32_t blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", in_lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512))) : 8u);
+    const uint32_t blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / WAVES_PER_BLOCK, (160 * 1024) / (lds + 512))));
     dim3 block(64 * WAVES_PER_BLOCK), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
 
     void (*kern)(RenderParams) = nullptr;

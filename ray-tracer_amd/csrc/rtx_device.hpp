@@ -11,6 +11,11 @@
 namespace rtxd {
 
 enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3 };
+// Word 7 of the entry a lane stands at is also that lane's walk state (see accel.hpp): 0 = box, ENT_END = walk
+// complete, anything else = primitive.  ST_IDLE marks a lane without a path.
+constexpr uint32_t ENT_END = 0xFFFFFFFEu;
+constexpr uint32_t ST_IDLE = 0xFFFFFFFFu;
+constexpr uint32_t ENT_BYTES = 32u;
 constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr float PI_F = 3.1415926535897932385f;  // utils.rs:4
 
@@ -110,29 +115,37 @@ __device__ __forceinline__ RayConst ray_const(const Ray& r) {
 
 // Aabb::hit (mesh.rs:512-538).  Checking end <= start once after the three axes is equivalent to the reference's
 // per-axis early return: start only grows and end only shrinks (NaN operands are ignored by max/min).
+//  strict: the reference's ordered select `if t0 < t1 {(t0,t1)} else {(t1,t0)}`, which matters when 0 * inf = NaN.
+//  fast  : min / max of the two plane distances.  Identical for ordinary values; a NaN (ray inside a bounding plane and
+//          parallel to it) drops out instead of taking the swapped branch -- the fast boxes are padded, so no primitive
+//          touches its box planes and such a ray cannot hit anything inside.
+template <bool STRICT>
 __device__ __forceinline__ bool slab_hit(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, float tmax) {
-    float t0 = (as_f(ea.x) - r.ox) * rc.ix, t1 = (as_f(ea.y) - r.ox) * rc.ix;
-    float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
-    tmin = fmaxf(tmin, lo);
-    tmax = fminf(tmax, hi);
-    t0 = (as_f(ea.z) - r.oy) * rc.iy;
-    t1 = (as_f(ea.w) - r.oy) * rc.iy;
-    lo = t0 < t1 ? t0 : t1;
-    hi = t0 < t1 ? t1 : t0;
-    tmin = fmaxf(tmin, lo);
-    tmax = fminf(tmax, hi);
-    t0 = (as_f(eb.x) - r.oz) * rc.iz;
-    t1 = (as_f(eb.y) - r.oz) * rc.iz;
-    lo = t0 < t1 ? t0 : t1;
-    hi = t0 < t1 ? t1 : t0;
-    tmin = fmaxf(tmin, lo);
-    tmax = fminf(tmax, hi);
+    const float x0 = (as_f(ea.x) - r.ox) * rc.ix, x1 = (as_f(ea.y) - r.ox) * rc.ix;
+    const float y0 = (as_f(ea.z) - r.oy) * rc.iy, y1 = (as_f(ea.w) - r.oy) * rc.iy;
+    const float z0 = (as_f(eb.x) - r.oz) * rc.iz, z1 = (as_f(eb.y) - r.oz) * rc.iz;
+    if (STRICT) {
+        float lo = x0 < x1 ? x0 : x1, hi = x0 < x1 ? x1 : x0;
+        tmin = fmaxf(tmin, lo);
+        tmax = fminf(tmax, hi);
+        lo = y0 < y1 ? y0 : y1;
+        hi = y0 < y1 ? y1 : y0;
+        tmin = fmaxf(tmin, lo);
+        tmax = fminf(tmax, hi);
+        lo = z0 < z1 ? z0 : z1;
+        hi = z0 < z1 ? z1 : z0;
+        tmin = fmaxf(tmin, lo);
+        tmax = fminf(tmax, hi);
+    } else {
+        tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+        tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+    }
     return !(tmax <= tmin);
 }
 
 struct Best {
     float t;       // running interval end = distance of the closest accepted hit so far
-    uint32_t ent;  // entry index of that hit, NO_HIT while none
+    uint32_t ent;  // byte offset of that hit's entry, NO_HIT while none
 };
 
 // Accept a candidate distance under the mode's rule.
@@ -140,11 +153,11 @@ struct Best {
 //  fast  : same closest hit, visited in another order: on an exact tie the primitive the reference tests
 //          first (lower rank) wins, as it does there because the later one needs t < tmax.
 template <bool STRICT>
-__device__ __forceinline__ bool in_range(float t, float tmin, const Best& b, uint32_t idx, const uint32_t* __restrict__ rank) {
+__device__ __forceinline__ bool in_range(float t, float tmin, const Best& b, uint32_t off, const uint32_t* __restrict__ rank) {
     if (STRICT) return tmin <= t && t < b.t;
     if (!(tmin <= t)) return false;
     if (t < b.t) return true;
-    return t == b.t && b.ent != NO_HIT && rank[idx] < rank[b.ent];
+    return t == b.t && b.ent != NO_HIT && rank[off / ENT_BYTES] < rank[b.ent / ENT_BYTES];
 }
 
 // Sphere::hit up to the accepted root (mesh.rs:113-133).
@@ -197,20 +210,20 @@ __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, u
     best.ent = idx;
 }
 
-// One step of the walk for the entry (ea, eb) at index idx; returns the next index.
+// One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
 template <bool STRICT>
-__device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t idx, const Ray& r, const RayConst& rc,
+__device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t off, const Ray& r, const RayConst& rc,
                                               float tmin, Best& best, const uint32_t* __restrict__ rank) {
-    uint32_t kind = eb.w & 15u;
-    if (kind == ENT_BOX) return slab_hit(ea, eb, r, rc, tmin, best.t) ? idx + 1 : eb.z;
+    if (eb.w == ENT_BOX) return slab_hit<STRICT>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
+    const uint32_t kind = eb.w & 15u;
     if (kind == ENT_SPHERE) {
-        sphere_test<STRICT>(ea, eb, r, rc, tmin, best, idx, rank);
+        sphere_test<STRICT>(ea, eb, r, rc, tmin, best, off, rank);
     } else {
-        uint32_t pi = eb.w >> 4;
-        bool tri = kind == ENT_TRI;
-        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, r, tmin, best, idx, rank);
+        const uint32_t pi = eb.w >> 4;
+        const bool tri = kind == ENT_TRI;
+        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, r, tmin, best, off, rank);
     }
-    return idx + 1;
+    return off + ENT_BYTES;
 }
 
 // ---------------------------------------------------------------------------------------------- hit record
