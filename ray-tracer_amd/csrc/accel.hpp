@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -147,7 +148,7 @@ struct PrimBox {
     uint32_t rank;  // tie-break rank
 };
 
-static inline void prim_bounds(const rtx_scene_desc_t& d, uint32_t kind, uint32_t i, float lo[3], float hi[3]) {
+static inline void prim_bounds(const rtx_scene_desc_t& d, uint32_t kind, uint32_t i, float lo[3], float hi[3], float coord_range) {
     if (kind == RTX_REF_SPHERE) {
         const float c0[3] = {d.sph_cx[i], d.sph_cy[i], d.sph_cz[i]};
         const float dc[3] = {d.sph_dx[i], d.sph_dy[i], d.sph_dz[i]};
@@ -178,7 +179,8 @@ static inline void prim_bounds(const rtx_scene_desc_t& d, uint32_t kind, uint32_
     float pad = 1e-3f * std::sqrt(diag2);
     for (int a = 0; a < 3; a++) {
         float m = std::fmax(std::fabs(lo[a]), std::fabs(hi[a]));
-        float p = pad + 4e-7f * m + 1e-30f;
+        // + the absolute error of the fused box test: ~1.2e-7 * (|origin| + |hit point|) <= 2.4e-7 * coord_range
+        float p = pad + 4e-7f * m + 3e-7f * coord_range + 1e-30f;
         lo[a] -= p;
         hi[a] += p;
     }
@@ -189,7 +191,8 @@ struct FastBuilder {
     const rtx_scene_desc_t& d;
     Threaded& out;
     static constexpr int NBINS = 16;
-    static constexpr uint32_t MAX_LEAF = 4;
+    uint32_t MAX_LEAF = 4;   // most primitives under one leaf box
+    float C_TRAV = 1.0f;     // cost of a box test in units of a primitive test
 
     FastBuilder(std::vector<PrimBox>& p, const rtx_scene_desc_t& d_, Threaded& o) : prims(p), d(d_), out(o) {}
 
@@ -262,7 +265,7 @@ struct FastBuilder {
         }
         // SAH: one box test costs about as much as a primitive test here, so compare (1 + split) against n
         bool make_leaf = n <= 1 || best_axis < 0 ||
-                         (n <= MAX_LEAF && !(parent_area > 0 && 1.0f + best_cost / parent_area < (float)n));
+                         (n <= MAX_LEAF && !(parent_area > 0 && C_TRAV + best_cost / parent_area < (float)n));
         if (make_leaf && n > MAX_LEAF) {
             // all centroids coincide: split the range in half to bound the leaf size
             uint32_t mid = begin + n / 2;
@@ -306,7 +309,7 @@ static inline void finalize(Threaded& t) {
 }
 
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.
-static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, std::string& err) {
+static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, float& coord_range, std::string& err) {
     StrictBuilder sb(d, strict);
     if (!sb.emit(d.root)) {
         err = sb.err;
@@ -315,17 +318,27 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     if (strict.n_prims == 0) { err = "empty scene: no primitive is reachable from the root"; return RTX_ERR_INVALID; }
     std::vector<PrimBox> prims;
     prims.reserve(sb.first_rank.size());
+    // coordinate range of the scene: every ray the render kernels trace starts at the camera or on a primitive
+    coord_range = 0.0f;
+    for (auto& kv : sb.first_rank) {
+        float lo[3], hi[3];
+        prim_bounds(d, RTX_REF_KIND(kv.first), RTX_REF_INDEX(kv.first), lo, hi, 0.0f);
+        for (int a = 0; a < 3; a++) {
+            if (lo[a] != lo[a] || hi[a] != hi[a]) { err = "NaN in primitive bounds"; return RTX_ERR_INVALID; }
+            coord_range = std::fmax(coord_range, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+        }
+    }
     for (auto& kv : sb.first_rank) {
         PrimBox p;
         p.ref = kv.first;
         p.rank = kv.second;
-        prim_bounds(d, RTX_REF_KIND(kv.first), RTX_REF_INDEX(kv.first), p.lo, p.hi);
-        for (int a = 0; a < 3; a++)
-            if (p.lo[a] != p.lo[a] || p.hi[a] != p.hi[a]) { err = "NaN in primitive bounds"; return RTX_ERR_INVALID; }
+        prim_bounds(d, RTX_REF_KIND(kv.first), RTX_REF_INDEX(kv.first), p.lo, p.hi, coord_range);
         prims.push_back(p);
     }
     std::sort(prims.begin(), prims.end(), [](const PrimBox& x, const PrimBox& y) { return x.rank < y.rank; });
     FastBuilder fb(prims, d, fast);
+    if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) fb.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RTX_SAH_CTRAV")) fb.C_TRAV = (float)std::atof(e);
     fb.build(0, (uint32_t)prims.size());
     if (strict.ents.size() >= (1u << 26) || fast.ents.size() >= (1u << 26)) { err = "scene too large for 32-bit entry offsets"; return RTX_ERR_INVALID; }
     finalize(strict);

@@ -53,6 +53,7 @@ struct rtx_scene {
     uint32_t* counters = nullptr;  // [0] item counter, [2..3] ray counter (u64)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 0;
+    float coord_range = 0.0f;    // largest |coordinate| the fast boxes were padded for
     bool full_features = false;  // scene uses image or noise textures (uv evaluation, Perlin tables)
 };
 
@@ -156,7 +157,7 @@ extern "C" void rtx_scene_destroy(rtx_scene_t* s) {
 static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     rtx_accel::Threaded strict, fast;
     std::string err;
-    int rc = rtx_accel::build(*d, strict, fast, err);
+    int rc = rtx_accel::build(*d, strict, fast, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
 
     HIP_TRY(hipGetDevice(&s->device));
@@ -261,7 +262,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     }
     if ((rc = upload(s, perlin, &s->dev.perlin)) != RTX_OK) return rc;
 
-    HIP_TRY(hipMalloc((void**)&s->counters, 64));
+    HIP_TRY(hipMalloc((void**)&s->counters, 128));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     return RTX_OK;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
     r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
     r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
     r.time = rays[i].time;
-    const RayConst rc = ray_const(r);
+    const RayConst rc = ray_const<STRICT ? SLAB_STRICT : SLAB_ROBUST>(r);
     Best best;
     best.t = tmax;
     best.ent = NO_HIT;
@@ -408,6 +409,7 @@ extern __shared__ uint4 smem[];
 template <bool STRICT, bool ENTS_IN_LDS, bool FULL>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
+    constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
     const DevScene& S = P.S;
     const uint4* __restrict__ gents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
@@ -425,6 +427,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     unsigned long long rays_traced = 0;
+#ifdef RTX_STAGE_COUNTERS
+    unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
+#endif
 
     // per-lane path state
     uint32_t off = 0;                            // byte offset of the entry the lane stands at
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     } while (0)
 #define RTX_BEGIN_WALK()                 \
     do {                                 \
-        rc = ray_const(ray);             \
+        rc = ray_const<SLAB>(ray);       \
         best.t = __builtin_inff();       \
         best.ent = NO_HIT;               \
         rays_traced++;                   \
@@ -485,6 +490,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
             const uint32_t n_prim = 64u - n_box - n_done - n_idle;
             const uint32_t n_serv = n_done + min(n_idle, pool_total - pool_next);
             if (n_box + n_prim + n_serv == 0) break;
+#ifdef RTX_STAGE_COUNTERS
+            sc[7]++;
+#endif
 
             if (n_box >= n_prim && n_box >= n_serv) {
                 // ---- extend, box stage: Aabb::hit for the lanes standing at a box; keep going while boxes stay the
@@ -492,8 +500,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
                 uint32_t nb;
                 do {
+#ifdef RTX_STAGE_COUNTERS
+                    sc[0]++;
+                    sc[1] += __popcll(__ballot(eb.w == ENT_BOX));
+#endif
                     if (eb.w == ENT_BOX) {
-                        const bool hit = slab_hit<STRICT>(ea, eb, ray, rc, tmin, best.t);
+                        const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, tmin, best.t);
                         off = hit ? off + ENT_BYTES : eb.z;
                         RTX_LOAD_ENTRY(off, ea, eb);
                     }
@@ -501,6 +513,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                 } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
             } else if (n_prim >= n_serv) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive
+#ifdef RTX_STAGE_COUNTERS
+                sc[2]++;
+                sc[3] += n_prim;
+#endif
                 if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
                     const uint32_t kind = eb.w & 15u;
                     if (kind == ENT_SPHERE) {
@@ -515,6 +531,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                 }
             } else {
                 // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
+#ifdef RTX_STAGE_COUNTERS
+                sc[4]++;
+                sc[5] += n_done;
+                sc[6] += min(n_idle, pool_total - pool_next);
+#endif
                 if (eb.w == ENT_END) {
                     eb.w = ST_IDLE;
                     if (best.ent == NO_HIT) {
@@ -620,6 +641,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     // one ray-count update per wave
     for (int o = 32; o > 0; o >>= 1) rays_traced += __shfl_down(rays_traced, o);
     if (lane == 0 && rays_traced) atomicAdd(P.ray_counter, rays_traced);
+#ifdef RTX_STAGE_COUNTERS
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(P.ray_counter + 1 + i, sc[i]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ partial, uint32_t n_batches, size_t n, float* __restrict__ accum) {
@@ -667,7 +692,14 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     HIP_TRY(hipGetDevice(&cur));
     if (cur != scene->device) return fail(RTX_ERR_INVALID, "scene lives on another device than the current one");
 
-    const uint32_t M = opts->traversal;
+    uint32_t M = opts->traversal;
+    if (M == RTX_TRAVERSAL_FAST) {
+        // the fused box test of the fast walk is padded for ray origins inside the scene's coordinate range
+        float cmax = std::fmax(std::fabs(cam->center[0]), std::fmax(std::fabs(cam->center[1]), std::fabs(cam->center[2])));
+        float dmax = 0.0f;
+        for (int k = 0; k < 3; k++) dmax = std::fmax(dmax, std::fmax(std::fabs(cam->defocus_disk_u[k]), std::fabs(cam->defocus_disk_v[k])));
+        if (!(cmax + 2.0f * dmax <= scene->coord_range)) M = RTX_TRAVERSAL_STRICT;
+    }
     RenderParams P;
     std::memset(&P, 0, sizeof(P));
     P.S = scene->dev;
@@ -687,7 +719,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.n_batches = (spp + P.batch - 1) / P.batch;
     P.n_items = n_tiles * P.n_batches;
     P.rr_start = opts->rr_start_depth;
-    P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 2));
+    P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
 
     const size_t npix3 = (size_t)cam->width * cam->height * 3;
     const size_t need = npix3 * sizeof(float) * P.n_batches;
@@ -702,7 +734,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.partial = scene->partial;
     P.item_counter = scene->counters;
     P.ray_counter = reinterpret_cast<unsigned long long*>(scene->counters + 2);
-    HIP_TRY(hipMemsetAsync(scene->counters, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(scene->counters, 0, 128, st));
 
     const size_t ent_bytes = (size_t)scene->n_ents[M] * 32;
     const size_t acc_bytes = WAVES_PER_BLOCK * ACC_FLOATS * sizeof(float);
@@ -742,6 +774,13 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
         stats->kernel_ms = ms;
         stats->n_launches = 1;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+#ifdef RTX_STAGE_COUNTERS
+        unsigned long long sc[8];
+        HIP_TRY(hipMemcpy(sc, scene->counters + 4, 64, hipMemcpyDeviceToHost));
+        double r = (double)nrays;
+        std::fprintf(stderr, "[stages] rays %.3g | box steps %.3g lanes/step %.1f tests/ray %.2f | prim steps %.3g lanes/step %.1f tests/ray %.2f | service %.3g shade lanes/pass %.1f gen lanes/pass %.1f | sched passes %.3g\n", r,
+                     (double)sc[0], (double)sc[1] / sc[0], sc[1] / r, (double)sc[2], (double)sc[3] / sc[2], sc[3] / r, (double)sc[4], (double)sc[5] / sc[4], (double)sc[6] / sc[4], (double)sc[7]);
+#endif
     }
     return RTX_OK;
 }

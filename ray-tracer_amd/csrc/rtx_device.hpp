@@ -100,15 +100,35 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 
 // ---------------------------------------------------------------------------------------------- closest-hit walk
+// How a walk evaluates its box tests.
+//   SLAB_STRICT  Aabb::hit exactly as the reference evaluates it (ordered select, (bound - origin) * (1 / d)).
+//   SLAB_ROBUST  same products, min / max instead of the ordered select: conservative for any ray (fast rtx_trace).
+//   SLAB_FMA     bound * inv + (-origin * inv) in one fused operation per plane, inv from the hardware reciprocal.
+//                Its absolute error is at most ~1.2e-7 * (|origin| + |hit point|) along an axis, which the fast boxes'
+//                padding covers as long as ray origins stay within the scene's coordinate range (render kernels).
+enum : int { SLAB_STRICT = 0, SLAB_ROBUST = 1, SLAB_FMA = 2 };
+
 struct RayConst {  // per-ray values the tests reuse (same expressions the reference re-evaluates per call)
     float ix, iy, iz;  // 1.0 / direction  (mesh.rs:517)
     float a;           // direction.length_squared()  (mesh.rs:116)
+    float nx, ny, nz;  // SLAB_FMA only: -(origin * inv)
 };
+template <int SLAB>
 __device__ __forceinline__ RayConst ray_const(const Ray& r) {
     RayConst c;
-    c.ix = 1.0f / r.dx;
-    c.iy = 1.0f / r.dy;
-    c.iz = 1.0f / r.dz;
+    if (SLAB == SLAB_FMA) {
+        c.ix = __builtin_amdgcn_rcpf(r.dx);
+        c.iy = __builtin_amdgcn_rcpf(r.dy);
+        c.iz = __builtin_amdgcn_rcpf(r.dz);
+        c.nx = -(r.ox * c.ix);
+        c.ny = -(r.oy * c.iy);
+        c.nz = -(r.oz * c.iz);
+    } else {
+        c.ix = 1.0f / r.dx;
+        c.iy = 1.0f / r.dy;
+        c.iz = 1.0f / r.dz;
+        c.nx = c.ny = c.nz = 0.0f;
+    }
     c.a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
     return c;
 }
@@ -116,15 +136,27 @@ __device__ __forceinline__ RayConst ray_const(const Ray& r) {
 // Aabb::hit (mesh.rs:512-538).  Checking end <= start once after the three axes is equivalent to the reference's
 // per-axis early return: start only grows and end only shrinks (NaN operands are ignored by max/min).
 //  strict: the reference's ordered select `if t0 < t1 {(t0,t1)} else {(t1,t0)}`, which matters when 0 * inf = NaN.
-//  fast  : min / max of the two plane distances.  Identical for ordinary values; a NaN (ray inside a bounding plane and
-//          parallel to it) drops out instead of taking the swapped branch -- the fast boxes are padded, so no primitive
-//          touches its box planes and such a ray cannot hit anything inside.
-template <bool STRICT>
+//  others: min / max of the two plane distances.  Identical for ordinary values; a NaN (ray inside a bounding plane and
+//          parallel to it, or inf - inf in the fused form) drops out of min / max, i.e. that axis does not cull.
+template <int SLAB>
 __device__ __forceinline__ bool slab_hit(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, float tmax) {
-    const float x0 = (as_f(ea.x) - r.ox) * rc.ix, x1 = (as_f(ea.y) - r.ox) * rc.ix;
-    const float y0 = (as_f(ea.z) - r.oy) * rc.iy, y1 = (as_f(ea.w) - r.oy) * rc.iy;
-    const float z0 = (as_f(eb.x) - r.oz) * rc.iz, z1 = (as_f(eb.y) - r.oz) * rc.iz;
-    if (STRICT) {
+    float x0, x1, y0, y1, z0, z1;
+    if (SLAB == SLAB_FMA) {
+        x0 = __builtin_fmaf(as_f(ea.x), rc.ix, rc.nx);
+        x1 = __builtin_fmaf(as_f(ea.y), rc.ix, rc.nx);
+        y0 = __builtin_fmaf(as_f(ea.z), rc.iy, rc.ny);
+        y1 = __builtin_fmaf(as_f(ea.w), rc.iy, rc.ny);
+        z0 = __builtin_fmaf(as_f(eb.x), rc.iz, rc.nz);
+        z1 = __builtin_fmaf(as_f(eb.y), rc.iz, rc.nz);
+    } else {
+        x0 = (as_f(ea.x) - r.ox) * rc.ix;
+        x1 = (as_f(ea.y) - r.ox) * rc.ix;
+        y0 = (as_f(ea.z) - r.oy) * rc.iy;
+        y1 = (as_f(ea.w) - r.oy) * rc.iy;
+        z0 = (as_f(eb.x) - r.oz) * rc.iz;
+        z1 = (as_f(eb.y) - r.oz) * rc.iz;
+    }
+    if (SLAB == SLAB_STRICT) {
         float lo = x0 < x1 ? x0 : x1, hi = x0 < x1 ? x1 : x0;
         tmin = fmaxf(tmin, lo);
         tmax = fminf(tmax, hi);
@@ -214,7 +246,7 @@ __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, u
 template <bool STRICT>
 __device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t off, const Ray& r, const RayConst& rc,
                                               float tmin, Best& best, const uint32_t* __restrict__ rank) {
-    if (eb.w == ENT_BOX) return slab_hit<STRICT>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
+    if (eb.w == ENT_BOX) return slab_hit<STRICT ? SLAB_STRICT : SLAB_ROBUST>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
     const uint32_t kind = eb.w & 15u;
     if (kind == ENT_SPHERE) {
         sphere_test<STRICT>(ea, eb, r, rc, tmin, best, off, rank);
@@ -285,12 +317,11 @@ __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, c
 }
 
 // ---------------------------------------------------------------------------------------------- textures
-// Rust `as i32` saturates and maps NaN to 0.
+// Rust `as i32` saturates and maps NaN to 0 -- exactly what v_cvt_i32_f32 does in hardware.
 __device__ __forceinline__ int32_t as_i32_sat(float v) {
-    if (!(v == v)) return 0;
-    if (v >= 2147483648.0f) return 0x7FFFFFFF;
-    if (v <= -2147483648.0f) return (int32_t)0x80000000;
-    return (int32_t)v;
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
 __device__ __forceinline__ uint32_t as_u32_sat(float v) {
     if (!(v == v) || v <= 0.0f) return 0;

@@ -118,7 +118,7 @@ def rtx():
     global _rtx
     if _rtx is not None:
         return _rtx
-    path = os.path.join(_DIR, "librtx.so")
+    path = os.environ.get("RTX_LIB") or os.path.join(_DIR, "librtx.so")
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it with `make -C {_DIR}` (hipcc, gfx950); there is no fallback path")
     L = C.CDLL(path, mode=C.RTLD_GLOBAL)
