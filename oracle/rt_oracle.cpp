@@ -474,8 +474,16 @@ struct Dielectric : Material {  // material.rs:137-179
         float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
         bool cannot_refract = ri * sin_theta > 1.0f;
         Vec3 dir;
-        // `||` short-circuits: the random number is drawn only when refraction is possible
-        if (cannot_refract || reflectance(cos_theta, ri) > tl_rng->gen_f32())
+        // `||` short-circuits: the random number is drawn only when refraction is possible.
+        // (mirror stream: every scatter consumes two draws, as the HIP kernels do; the first is this one)
+        float xi = 0.0f;
+        bool drawn = false;
+        if (tl_rng->kind == 1) {
+            xi = tl_rng->gen_f32();
+            (void)tl_rng->gen_f32();
+            drawn = true;
+        }
+        if (cannot_refract || reflectance(cos_theta, ri) > (drawn ? xi : tl_rng->gen_f32()))
             dir = reflect(unit_dir, hit.normal);
         else
             dir = refract(unit_dir, hit.normal, ri);

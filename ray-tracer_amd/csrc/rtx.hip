@@ -472,10 +472,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
         const uint32_t tile = item % n_tiles, batch = item / n_tiles;
         const uint32_t tx = (tile % P.tiles_x) * TILE, ty = (tile / P.tiles_x) * TILE;
         const uint32_t vw = min((uint32_t)TILE, C.width - tx), vh = min((uint32_t)TILE, C.height - ty);
-        const uint32_t npix = vw * vh;
         const uint32_t s0 = P.sample_begin + batch * P.batch;
         const uint32_t ns = min(P.batch, P.sample_end - s0);
-        const uint32_t pool_total = npix * ns;
+        const uint32_t pool_total = 64u * ns;  // pool entry q = (sample q / 64, tile slot q % 64); slots outside the image are skipped
         uint32_t pool_next = 0;  // wave-uniform
 
         acc[lane] = 0.0f;
@@ -552,9 +551,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                             const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
                                                                     : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
                             const bool want_uv = (S.mats[mat].w & 1u) != 0u;
-                            h = want_uv ? make_hit<true>(S, ha, hb, ray, best.t) : make_hit<false>(S, ha, hb, ray, best.t);
+                            h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
                         } else {
-                            h = make_hit<false>(S, ha, hb, ray, best.t);
+                            h = make_hit<false, false>(S, ha, hb, ray, best.t);
                         }
                         ScatterOut so = shade<FULL>(S, ray, h, rng);
                         if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
@@ -568,16 +567,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                             bb *= so.ab;
                             depth_left--;
                             bool alive = depth_left > 0;
-                            if (alive && P.rr_start && (C.max_depth - depth_left) >= P.rr_start) {
-                                // Russian roulette on the largest |throughput| component (albedos may be negative)
-                                const float q = fminf(1.0f, fmaxf(fmaxf(fabsf(br), fabsf(bg)), fabsf(bb)));
-                                if (rng_f32(rng) >= q) {
-                                    alive = false;
-                                } else {
-                                    const float iq = 1.0f / q;
-                                    br *= iq;
-                                    bg *= iq;
-                                    bb *= iq;
+                            if (P.rr_start != 0u) {  // wave-uniform: the reference has no Russian roulette
+                                if (alive && (C.max_depth - depth_left) >= P.rr_start) {
+                                    // on the largest |throughput| component (albedos may be negative)
+                                    const float q = fminf(1.0f, fmaxf(fmaxf(fabsf(br), fabsf(bg)), fabsf(bb)));
+                                    if (rng_f32(rng) >= q) {
+                                        alive = false;
+                                    } else {
+                                        const float iq = __builtin_amdgcn_rcpf(q);
+                                        br *= iq;
+                                        bg *= iq;
+                                        bb *= iq;
+                                    }
                                 }
                             }
                             if (alive) {
@@ -592,10 +593,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                 const unsigned long long idle = __ballot(eb.w == ST_IDLE);
                 if (idle && pool_next < pool_total) {
                     const uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    if (eb.w == ST_IDLE && my < pool_total) {
-                        slot = my % npix;
-                        const uint32_t sample = s0 + my / npix;
-                        const uint32_t x = tx + slot % vw, y = ty + slot / vw;
+                    const uint32_t my_slot = my & 63u;
+                    const uint32_t x = tx + (my_slot & 7u), y = ty + (my_slot >> 3);
+                    if (eb.w == ST_IDLE && my < pool_total && (my_slot & 7u) < vw && (my_slot >> 3) < vh) {
+                        slot = my_slot;
+                        const uint32_t sample = s0 + (my >> 6);
                         rng = rng_init(P.seed, y * C.width + x, sample);
                         const float ox = rng_f32(rng) - 0.5f;
                         const float oy = rng_f32(rng) - 0.5f;
@@ -628,8 +630,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
         }
 
         // ---- write the tile's sums into this batch's partial image (each pixel of each batch has one writer)
-        if (lane < npix) {
-            const uint32_t x = tx + lane % vw, y = ty + lane / vw;
+        if ((lane & 7u) < vw && (lane >> 3) < vh) {
+            const uint32_t x = tx + (lane & 7u), y = ty + (lane >> 3);
             float* dst = P.partial + ((size_t)batch * C.height * C.width + (size_t)y * C.width + x) * 3;
             dst[0] = acc[lane * 3 + 0];
             dst[1] = acc[lane * 3 + 1];

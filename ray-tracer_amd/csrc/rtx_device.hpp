@@ -276,7 +276,9 @@ __device__ __forceinline__ void sphere_uv(float nx, float ny, float nz, float& u
 }
 
 // The rest of Sphere::hit / Quad::hit after the root is accepted, plus Hit::new (mesh.rs:33-51, :135-138, :214-220).
-template <bool WANT_UV>
+// EXACT = true divides by the radius as the reference does (bit-identical normals, rtx_trace); false multiplies by the
+// hardware reciprocal (normals within ~2 ulp, far inside the 1e-5 tolerance; used where only shading consumes them).
+template <bool WANT_UV, bool EXACT = true>
 __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, const uint4& eb, const Ray& r, float t) {
     HitRec h;
     uint32_t kind = eb.w & 15u, pi = eb.w >> 4;
@@ -289,9 +291,16 @@ __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, c
         float cy = as_f(ea.y) + as_f(eb.x) * r.time;
         float cz = as_f(ea.z) + as_f(eb.y) * r.time;
         float radius = as_f(eb.z);
-        nx = (h.px - cx) / radius;
-        ny = (h.py - cy) / radius;
-        nz = (h.pz - cz) / radius;
+        if (EXACT) {
+            nx = (h.px - cx) / radius;
+            ny = (h.py - cy) / radius;
+            nz = (h.pz - cz) / radius;
+        } else {
+            const float inv_r = __builtin_amdgcn_rcpf(radius);
+            nx = (h.px - cx) * inv_r;
+            ny = (h.py - cy) * inv_r;
+            nz = (h.pz - cz) * inv_r;
+        }
         h.u = 0.0f;
         h.v = 0.0f;
         if (WANT_UV) sphere_uv(nx, ny, nz, h.u, h.v);
@@ -411,7 +420,7 @@ __device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float
 // ---------------------------------------------------------------------------------------------- materials
 // material.rs:13-17; powi(5) as llvm.powi expands it: x * ((x*x)*(x*x))
 __device__ __forceinline__ float reflectance(float cosine, float ri) {
-    float r0 = (1.0f - ri) / (1.0f + ri);
+    float r0 = (1.0f - ri) * __builtin_amdgcn_rcpf(1.0f + ri);
     r0 *= r0;
     float b = 1.0f - cosine;
     float b2 = b * b;
@@ -427,9 +436,14 @@ struct ScatterOut {
 };
 
 // Material::emitted + Material::scatter for the hit (camera.rs:128-130; material.rs:70-96, :104-119, :149-173,
-// :198-206, :231-240).  Random draws come in the order the reference makes them.
+// :198-206, :231-240), arranged for a wave whose lanes hold different materials: the two random draws, the unit
+// vector and the texture lookup that several materials need are evaluated once, ahead of the per-material part.
+// Every scatter consumes exactly two draws of the path's stream (the dielectric uses the first as its xi).
+// Shading arithmetic only has to agree with the reference within tolerance (the streams differ anyway), so this
+// function may fuse multiply-adds and uses the hardware reciprocal / reciprocal square root.
 template <bool FULL>
 __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitRec& h, Rng& rng) {
+#pragma clang fp contract(fast)
     ScatterOut o;
     o.scattered = false;
     o.ar = o.ag = o.ab = 0.0f;
@@ -439,72 +453,73 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
     o.ray.oy = h.py;
     o.ray.oz = h.pz;
     o.ray.time = rin.time;
-    o.ray.dx = o.ray.dy = o.ray.dz = 0.0f;
+    // shared by all materials: two draws, a uniform unit vector (utils.rs:37-39), the texture colour
+    const float u1 = rng_f32(rng);
+    const float u2 = rng_f32(rng);
+    const float rz = 1.0f - 2.0f * u1;
+    const float rr = __builtin_sqrtf(fmaxf(0.0f, 1.0f - rz * rz));
+    const float rx = rr * __builtin_amdgcn_cosf(u2);
+    const float ry = rr * __builtin_amdgcn_sinf(u2);
+    float tr = 1.0f, tg = 1.0f, tb = 1.0f;
+    if (m.x != RTX_MAT_DIELECTRIC) tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, tr, tg, tb);
+    float dx = 0.0f, dy = 0.0f, dz = 0.0f;
     if (m.x == RTX_MAT_LAMBERTIAN) {
-        float rx, ry, rz;
-        random_unit_vec(rng, rx, ry, rz);
-        float dx = h.nx + rx, dy = h.ny + ry, dz = h.nz + rz;
+        dx = h.nx + rx;
+        dy = h.ny + ry;
+        dz = h.nz + rz;
         const float s = 1e-8f;  // near_zero (utils.rs:41-44)
         if (fabsf(dx) < s && fabsf(dy) < s && fabsf(dz) < s) {
             dx = h.nx;
             dy = h.ny;
             dz = h.nz;
         }
-        tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
-        o.ray.dx = dx;
-        o.ray.dy = dy;
-        o.ray.dz = dz;
         o.scattered = true;
     } else if (m.x == RTX_MAT_METAL) {
         // reflect(ray.direction, normal) on the UN-normalised direction, plus roughness * unit vector (material.rs:107-108)
-        float k = 2.0f * dot3(rin.dx, rin.dy, rin.dz, h.nx, h.ny, h.nz);
-        float rx, ry, rz;
-        random_unit_vec(rng, rx, ry, rz);
-        float rough = as_f(m.z);
-        float dx = (rin.dx - k * h.nx) + (rough * rx);
-        float dy = (rin.dy - k * h.ny) + (rough * ry);
-        float dz = (rin.dz - k * h.nz) + (rough * rz);
-        o.ray.dx = dx;
-        o.ray.dy = dy;
-        o.ray.dz = dz;
-        if (dot3(dx, dy, dz, h.nx, h.ny, h.nz) > 0.0f) {
-            tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
-            o.scattered = true;
-        }
+        const float k = 2.0f * dot3(rin.dx, rin.dy, rin.dz, h.nx, h.ny, h.nz);
+        const float rough = as_f(m.z);
+        dx = (rin.dx - k * h.nx) + (rough * rx);
+        dy = (rin.dy - k * h.ny) + (rough * ry);
+        dz = (rin.dz - k * h.nz) + (rough * rz);
+        o.scattered = dot3(dx, dy, dz, h.nx, h.ny, h.nz) > 0.0f;
     } else if (m.x == RTX_MAT_DIELECTRIC) {
         // Hit::front_face is always true (mesh.rs:47) so ri = 1 / refraction_index on entry AND exit (material.rs:151-155)
-        float ri = 1.0f / as_f(m.z);
-        float inv_len = 1.0f / __builtin_sqrtf(dot3(rin.dx, rin.dy, rin.dz, rin.dx, rin.dy, rin.dz));
-        float ux = rin.dx * inv_len, uy = rin.dy * inv_len, uz = rin.dz * inv_len;
-        float cos_theta = -fminf(dot3(ux, uy, uz, h.nx, h.ny, h.nz), 1.0f);
-        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
-        bool cannot_refract = ri * sin_theta > 1.0f;
-        float dx, dy, dz;
-        if (cannot_refract || reflectance(cos_theta, ri) > rng_f32(rng)) {
-            float k = 2.0f * dot3(ux, uy, uz, h.nx, h.ny, h.nz);
+        const float ri = __builtin_amdgcn_rcpf(as_f(m.z));
+        const float inv_len = __builtin_amdgcn_rsqf(dot3(rin.dx, rin.dy, rin.dz, rin.dx, rin.dy, rin.dz));
+        const float ux = rin.dx * inv_len, uy = rin.dy * inv_len, uz = rin.dz * inv_len;
+        const float udn = dot3(ux, uy, uz, h.nx, h.ny, h.nz);
+        const float cos_theta = -fminf(udn, 1.0f);
+        const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        const bool cannot_refract = ri * sin_theta > 1.0f;
+        if (cannot_refract || reflectance(cos_theta, ri) > u1) {
+            const float k = 2.0f * udn;
             dx = ux - k * h.nx;
             dy = uy - k * h.ny;
             dz = uz - k * h.nz;
         } else {  // refract (material.rs:23-28)
-            float ct = -fminf(dot3(ux, uy, uz, h.nx, h.ny, h.nz), 1.0f);
-            float ppx = ri * (ux + ct * h.nx), ppy = ri * (uy + ct * h.ny), ppz = ri * (uz + ct * h.nz);
-            float par = -__builtin_sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
+            const float ppx = ri * (ux + cos_theta * h.nx), ppy = ri * (uy + cos_theta * h.ny), ppz = ri * (uz + cos_theta * h.nz);
+            const float par = -__builtin_sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
             dx = ppx + par * h.nx;
             dy = ppy + par * h.ny;
             dz = ppz + par * h.nz;
         }
-        o.ar = o.ag = o.ab = 1.0f;
-        o.ray.dx = dx;
-        o.ray.dy = dy;
-        o.ray.dz = dz;
         o.scattered = true;
     } else if (m.x == RTX_MAT_DIFFUSE_LIGHT) {
-        tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.er, o.eg, o.eb);
+        o.er = tr;
+        o.eg = tg;
+        o.eb = tb;
     } else if (m.x == RTX_MAT_ISOTROPIC) {
-        random_unit_vec(rng, o.ray.dx, o.ray.dy, o.ray.dz);
-        tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, o.ar, o.ag, o.ab);
+        dx = rx;
+        dy = ry;
+        dz = rz;
         o.scattered = true;
     }
+    o.ar = tr;
+    o.ag = tg;
+    o.ab = tb;
+    o.ray.dx = dx;
+    o.ray.dy = dy;
+    o.ray.dz = dz;
     return o;
 }
 
