@@ -386,6 +386,7 @@ struct RenderParams {
     uint32_t n_items;
     uint32_t rr_start;
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
+    uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
     uint32_t* item_counter;
     unsigned long long* ray_counter;
     float* partial;       // [n_batches][H][W][3]
@@ -493,7 +494,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
             sc[7]++;
 #endif
 
-            if (n_box >= n_prim && n_box >= n_serv) {
+            // run the stage with the best score: queue length weighted by a per-stage constant (eighths)
+            const uint32_t sc_box = n_box * 8u, sc_prim = n_prim * P.w_prim, sc_serv = n_serv * P.w_serv;
+            if (n_box != 0u && sc_box >= sc_prim && sc_box >= sc_serv) {
                 // ---- extend, box stage: Aabb::hit for the lanes standing at a box; keep going while boxes stay the
                 //      largest queue (one ballot per step: everything that is not BOX is "the rest")
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                     }
                     nb = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
                 } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
-            } else if (n_prim >= n_serv) {
+            } else if (n_prim != 0u && (sc_prim >= sc_serv || n_serv == 0u)) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive
 #ifdef RTX_STAGE_COUNTERS
                 sc[2]++;
@@ -722,6 +725,8 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.n_items = n_tiles * P.n_batches;
     P.rr_start = opts->rr_start_depth;
     P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
+    P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 12));
+    P.w_serv = std::max<uint32_t>(1u, env_u32("RTX_W_SERV", 5));
 
     const size_t npix3 = (size_t)cam->width * cam->height * 3;
     const size_t need = npix3 * sizeof(float) * P.n_batches;
