@@ -706,6 +706,47 @@ struct Quad : Mesh {  // mesh.rs:190-257
     const Aabb& bounding_box() const override { return bbox; }
 };
 
+// Triangle: NOT in the reference (it has no triangle type and no mesh loader).  Build-defined restatement used as the
+// parity target for the triangle configurations: exactly Quad's plane / alpha / beta arithmetic (mesh.rs:202-221,
+// :229-246) with Q = v0, u = v1 - v0, v = v2 - v0 and the triangle's domain alpha >= 0, beta >= 0, alpha + beta <= 1.
+struct Triangle : Mesh {
+    Vec3 q, u, v, normal, w;
+    float d = 0;
+    std::shared_ptr<Material> material;
+    Aabb bbox;
+    uint32_t prim_id = 0;
+    static std::shared_ptr<Triangle> make(Vec3 v0, Vec3 v1, Vec3 v2, std::shared_ptr<Material> m) {
+        auto t = std::make_shared<Triangle>();
+        t->q = v0;
+        t->u = v1 - v0;
+        t->v = v2 - v0;
+        Vec3 n = cross(t->u, t->v);
+        t->normal = normalize(n);
+        t->d = dot(t->normal, t->q);
+        t->w = n / dot(n, n);
+        t->material = m;
+        Vec3 lo(rmin(v0.x, rmin(v1.x, v2.x)), rmin(v0.y, rmin(v1.y, v2.y)), rmin(v0.z, rmin(v1.z, v2.z)));
+        Vec3 hi(rmax(v0.x, rmax(v1.x, v2.x)), rmax(v0.y, rmax(v1.y, v2.y)), rmax(v0.z, rmax(v1.z, v2.z)));
+        t->bbox = Aabb::from_extremes(lo, hi);
+        return t;
+    }
+    Hit hit(const Ray& ray, const Interval& ray_t) const override {
+        tl_cnt.quad_tests++;
+        float denom = dot(normal, ray.direction);
+        if (std::fabs(denom) < 1e-8f) return Hit();
+        float t = (d - dot(normal, ray.origin)) / denom;
+        if (!ray_t.contains(t)) return Hit();
+        Vec3 intersection = ray.get_point(t);
+        Vec3 planar = intersection - q;
+        float alpha = dot(w, cross(planar, v));
+        float beta = dot(w, cross(u, planar));
+        if (!(alpha >= 0.0f && beta >= 0.0f && alpha + beta <= 1.0f)) return Hit();
+        tl_cnt.quad_hits++;
+        return hit_new(ray, t, normal, material.get(), alpha, beta, prim_id);
+    }
+    const Aabb& bounding_box() const override { return bbox; }
+};
+
 struct Cube : Mesh {  // mesh.rs:259-322: a World of six quads sharing one material
     World world;
     static std::shared_ptr<Cube> make(Vec3 a, Vec3 b, std::shared_ptr<Material> m, uint32_t first_prim_id) {  // mesh.rs:272-321
@@ -1063,6 +1104,11 @@ orc_mesh* orc_quad(const float* q, const float* u, const float* v, orc_mat* m, u
     s->prim_id = prim_id;
     return new orc_mesh{s};
 }
+orc_mesh* orc_triangle(const float* a, const float* b, const float* c, orc_mat* m, uint32_t prim_id) {
+    auto t = Triangle::make(v3(a), v3(b), v3(c), m->p);
+    t->prim_id = prim_id;
+    return new orc_mesh{t};
+}
 orc_mesh* orc_cube(const float* a, const float* b, orc_mat* m, uint32_t first_prim_id) {
     return new orc_mesh{Cube::make(v3(a), v3(b), m->p, first_prim_id)};
 }
@@ -1082,6 +1128,19 @@ int orc_world_push(orc_mesh* world, orc_mesh* m) {
     World* w = dynamic_cast<World*>(world->p.get());
     if (!w) return -1;
     w->push(m->p);
+    return 0;
+}
+int orc_world_push_trimesh(orc_mesh* world, const float* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_tris,
+                           orc_mat* m, uint32_t first_prim_id) {
+    World* w = dynamic_cast<World*>(world->p.get());
+    if (!w) return -1;
+    for (uint32_t i = 0; i < n_tris; i++) {
+        uint32_t a = indices[3 * i], b = indices[3 * i + 1], c = indices[3 * i + 2];
+        if (a >= n_vertices || b >= n_vertices || c >= n_vertices) return -1;
+        auto t = Triangle::make(v3(vertices + 3 * a), v3(vertices + 3 * b), v3(vertices + 3 * c), m->p);
+        t->prim_id = first_prim_id + i;
+        w->push(t);
+    }
     return 0;
 }
 // Bvh::from(&world)   (main.rs:577).  An empty world recurses without bound in the reference; refuse it.
@@ -1114,6 +1173,8 @@ static void dfs_leaves(const Mesh* m, std::vector<uint32_t>& out) {
         out.push_back(s->prim_id);
     } else if (auto q = dynamic_cast<const Quad*>(m)) {
         out.push_back(q->prim_id);
+    } else if (auto t3 = dynamic_cast<const Triangle*>(m)) {
+        out.push_back(t3->prim_id);
     } else if (auto cm = dynamic_cast<const ConstantMedium*>(m)) {
         out.push_back(cm->prim_id);
     }

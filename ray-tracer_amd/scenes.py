@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from .scene import (Bvh, CameraConfig, CheckerTexture, ConstantMedium, Cube, Dielectric, DiffuseLight, ImageTexture,
-                    Lambertian, Metal, NoiseTexture, Quad, RotateY, SolidTexture, Sphere, Translate, World, vec3)
+                    Lambertian, Metal, NoiseTexture, Quad, RotateY, SolidTexture, Sphere, Translate, TriangleMesh, World, vec3)
 
 F = np.float32
 _EARTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "earthmap_rgb8.png")
@@ -101,6 +101,8 @@ CAMERAS = {
 }
 # the reference has no default scene (the scene argument is required, main.rs:560); `default` is the
 # five-sphere scene below under the bouncing-spheres camera at 400x225, 16 spp, depth 50
+CAMERAS["triangle-mesh"] = lambda: CAMERAS["bouncing-spheres"]().replace(width=1920, height=1080, samples_per_pixel=256, defocus_angle=0.0)
+CAMERAS["mixed"] = lambda: CAMERAS["bouncing-spheres"]().replace(width=3840, height=2160, samples_per_pixel=4096)
 CAMERAS["default"] = lambda: CAMERAS["bouncing-spheres"]().replace(width=400, height=225, samples_per_pixel=16)
 
 
@@ -270,6 +272,53 @@ def default_scene(seed=0):
     return world
 
 
+def displaced_sphere_mesh(n_lat, seed=1, center=(0.0, 1.2, 0.0), radius=1.2):
+    """Synthetic triangle mesh (the reference has no triangle type or mesh loader, and no mesh asset is available
+    offline): a latitude / longitude tessellation of a sphere whose radius is displaced by a few seeded sinusoids.
+    n_lat rings x 2*n_lat segments -> 4 * n_lat * (n_lat - 1) triangles (n_lat = 500 gives 998 000)."""
+    rng = np.random.default_rng(seed)
+    n_lon = 2 * n_lat
+    k = rng.integers(2, 9, size=(4, 2)).astype(np.float64)
+    ph = rng.uniform(0, 2 * np.pi, size=4)
+    amp = np.array([0.10, 0.06, 0.04, 0.03])
+    theta = np.linspace(0.0, np.pi, n_lat + 1)[:, None]
+    phi = np.linspace(0.0, 2 * np.pi, n_lon, endpoint=False)[None, :]
+    disp = sum(a * np.sin(kk[0] * theta + p) * np.cos(kk[1] * phi) for a, kk, p in zip(amp, k, ph))
+    r = radius * (1.0 + disp * np.sin(theta) ** 2)  # undisplaced at the poles so that they stay single points
+    x = r * np.sin(theta) * np.cos(phi) + center[0]
+    y = r * np.cos(theta) + center[1] + 0 * phi
+    z = r * np.sin(theta) * np.sin(phi) + center[2]
+    verts = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(F)
+    i, j = np.meshgrid(np.arange(n_lat), np.arange(n_lon), indexing="ij")
+    a = i * n_lon + j
+    b = i * n_lon + (j + 1) % n_lon
+    c = (i + 1) * n_lon + j
+    d = (i + 1) * n_lon + (j + 1) % n_lon
+    t1 = np.stack([a, c, b], axis=-1)[1:]      # the first ring's upper triangles are degenerate at the pole
+    t2 = np.stack([b, c, d], axis=-1)[:-1]     # likewise the last ring's lower triangles
+    tris = np.concatenate([t1.reshape(-1, 3), t2.reshape(-1, 3)]).astype(np.uint32)
+    return verts, tris
+
+
+def triangle_mesh(seed=1, n_lat=40):
+    """Triangle-mesh scene: the displaced-sphere mesh (Lambertian) on the checker ground under the default background."""
+    world = World()
+    world.push(Sphere.stationary(vec3(0.0, -1000.0, 0.0), 1000.0, _checker_ground()))
+    verts, tris = displaced_sphere_mesh(n_lat, seed)
+    world.push(TriangleMesh(verts, tris, Lambertian.rgb(0.7, 0.45, 0.2)))
+    return world
+
+
+def mixed_scene(seed=1, n_lat=40):
+    """Mixed scene: the five default spheres (earth texture, metal, glass) + a triangle mesh + three more glass spheres."""
+    world = default_scene(seed)
+    verts, tris = displaced_sphere_mesh(n_lat, seed, center=(-1.0, 0.8, 3.0), radius=0.8)
+    world.push(TriangleMesh(verts, tris, Lambertian.rgb(0.25, 0.5, 0.7)))
+    for c in [(2.5, 0.4, 4.0), (-2.5, 0.4, 1.5), (0.5, 0.3, 4.5)]:
+        world.push(Sphere.stationary(vec3(*c), c[1], Dielectric(1.5)))
+    return world
+
+
 WORLDS = {
     "bouncing-spheres": bouncing_spheres,
     "checkered-spheres": checkered_spheres,
@@ -281,10 +330,12 @@ WORLDS = {
     "cornell-smoke": cornell_smoke,
     "final-scene": final_scene,
     "default": default_scene,
+    "triangle-mesh": triangle_mesh,
+    "mixed": mixed_scene,
 }
 
 
-def make(name, seed=1, **camera_overrides):
+def make(name, seed=1, world_args=None, **camera_overrides):
     """(CameraConfig, Bvh) for a scene name; camera_overrides mirror the CLI's -w/--height/-s/-d/-v (main.rs:567-574)."""
     cfg = CAMERAS[name]().replace(**camera_overrides)
-    return cfg, Bvh.from_world(WORLDS[name](seed))
+    return cfg, Bvh.from_world(WORLDS[name](seed, **(world_args or {})))

@@ -103,3 +103,11 @@ def test_no_gpu_means_loud_failure(render, scenes):
     with pytest.raises(render.RtxError) as e:
         render.Scene(bvh, upload=True)
     assert e.value.code == render.RTX_ERR_NO_DEVICE
+
+
+def test_triangle_mesh_flattens_like_the_oracle(render, oracle, scenes):
+    cfg, bvh = scenes.make("triangle-mesh", seed=2, world_args=dict(n_lat=12))
+    hs, om = render.Scene(bvh, upload=False), oracle.OracleMesh(bvh)
+    assert hs.desc.n_tris == 4 * 12 * 11 and hs.n_prims == om.n_prims == 1 + 4 * 12 * 11
+    assert np.array_equal(hs.leaf_order(), om.leaf_order())
+    assert np.array_equal(hs.node_boxes(), om.node_boxes())
