@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--rr", type=int, default=0, help="Russian roulette start depth (0 = off, as in the reference)")
     ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mesh-nlat", type=int, default=0, help="triangle-mesh / mixed scenes: latitude rings of the synthetic mesh (500 = 998k triangles)")
     ap.add_argument("--save", default=None, help="write the frame to this PNG (rank 0)")
     args = ap.parse_args()
 
@@ -85,8 +86,9 @@ def main():
     scenes = importlib.import_module("ray-tracer_amd.scenes")
     parallel = importlib.import_module("ray-tracer_amd.parallel")
 
-    cfg, bvh = scenes.make(args.scene, seed=args.seed, width=args.width, height=args.height, samples_per_pixel=args.spp,
-                           max_depth=args.depth)
+    world_args = {"n_lat": args.mesh_nlat} if args.mesh_nlat else None
+    cfg, bvh = scenes.make(args.scene, seed=args.seed, world_args=world_args, width=args.width, height=args.height,
+                           samples_per_pixel=args.spp, max_depth=args.depth)
     scene = render.Scene(bvh)  # flatten + upload: resident in HBM before the timed region
     cam = render.Camera(cfg)
     trav = render.TRAVERSAL_STRICT if args.traversal == "strict" else render.TRAVERSAL_FAST

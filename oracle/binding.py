@@ -49,6 +49,7 @@ def lib():
     L.orc_camera_constants.argtypes = [V, C.c_float * 19]
     L.orc_camera_center_rays.argtypes = [V, C.c_float, V]
     L.orc_trace.argtypes = [V, V, C.c_size_t, C.c_float, C.c_float, C.c_uint64, V]
+    L.orc_trace_mirror.argtypes = [V, V, C.c_size_t, C.c_float, C.c_float, C.c_uint64, V]
     L.orc_render.argtypes = [V, V, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_int, V, V]
     L.orc_srgb_u8.restype = C.c_uint8
     L.orc_srgb_u8.argtypes = [C.c_float]
@@ -96,10 +97,12 @@ class OracleMesh:
         lib().orc_bvh_node_boxes(self.handle, capi.fptr(out), n)
         return out
 
-    def trace(self, rays, tmin=0.001, tmax=float("inf"), seed=0):
+    def trace(self, rays, tmin=0.001, tmax=float("inf"), seed=0, mirror=False):
+        """mirror=True keys the generator a ConstantMedium draws from on (seed, ray index), as rtx_trace does."""
         rays = np.ascontiguousarray(rays, dtype=capi.RAY_DTYPE)
         hits = np.zeros(len(rays), dtype=capi.HIT_DTYPE)
-        lib().orc_trace(self.handle, rays.ctypes.data, len(rays), tmin, tmax, seed, hits.ctypes.data)
+        fn = lib().orc_trace_mirror if mirror else lib().orc_trace
+        fn(self.handle, rays.ctypes.data, len(rays), tmin, tmax, seed, hits.ctypes.data)
         return hits
 
 

@@ -1236,11 +1236,14 @@ void orc_camera_center_rays(orc_camera* c, float time, orc_ray_t* out) {
 
 // Closest hit of each ray in [tmin, tmax)  (the Mesh::hit contract, mesh.rs:17-21).
 // `seed` feeds the generator ConstantMedium::hit draws from (mesh.rs:659); other meshes ignore it.
-void orc_trace(orc_mesh* m, const orc_ray_t* rays, size_t n, float tmin, float tmax, uint64_t seed, orc_hit_t* out) {
+//   rng_kind 0: one ChaCha12 stream for the whole call;  1: the mirror stream keyed (seed, ray index, 0) per ray, which is
+//   what rtx_trace uses, so that media can be compared hit for hit.
+static void trace_impl(orc_mesh* m, const orc_ray_t* rays, size_t n, float tmin, float tmax, uint64_t seed, int rng_kind, orc_hit_t* out) {
     Rng rng;
     rng.seed_faithful(seed, 0x7261795fu);
     tl_rng = &rng;
     for (size_t i = 0; i < n; i++) {
+        if (rng_kind == 1) rng.seed_mirror(seed, (uint32_t)i, 0);
         Ray r(Vec3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), Vec3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].time);
         Hit h = m->p->hit(r, Interval(tmin, tmax));
         orc_hit_t& o = out[i];
@@ -1258,6 +1261,12 @@ void orc_trace(orc_mesh* m, const orc_ray_t* rays, size_t n, float tmin, float t
     }
     tl_rng = nullptr;
     flush_counters();
+}
+void orc_trace(orc_mesh* m, const orc_ray_t* rays, size_t n, float tmin, float tmax, uint64_t seed, orc_hit_t* out) {
+    trace_impl(m, rays, n, tmin, tmax, seed, 0, out);
+}
+void orc_trace_mirror(orc_mesh* m, const orc_ray_t* rays, size_t n, float tmin, float tmax, uint64_t seed, orc_hit_t* out) {
+    trace_impl(m, rays, n, tmin, tmax, seed, 1, out);
 }
 
 // Camera::render (camera.rs:98-122) for the sample index range [sample_begin, sample_end).

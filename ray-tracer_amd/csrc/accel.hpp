@@ -1,15 +1,27 @@
 // Host-side construction of the traversal data the kernels walk.
 //
 // Both traversal modes use the same device structure: a "threaded" array of 32-byte entries in depth-first
-// order.  An entry is either a box (six bounds + the index to jump to when the ray misses it) or a primitive
-// (spheres are stored inline, planar primitives by index); a hit box falls through to the next entry.  Walking
-// the array front to back therefore IS a left-first depth-first traversal without a stack.
+// order.  An entry is a box (six bounds + where to jump when the ray misses it; a hit falls through to the next
+// entry), a primitive (spheres inline, planar primitives by index) or a bracket (transform enter / leave, medium
+// begin / end).  Walking the array front to back therefore IS a left-first depth-first traversal without a stack.
 //
-//  strict: the array is the reference's own tree (Bvh::from, mesh.rs:560-605, handed over in bvh_nodes) with
-//          the reference's padded, origin-including boxes, so Bvh::hit (mesh.rs:608-620) is reproduced test
-//          for test, cull for cull.
-//  fast  : a binned-SAH tree built here over tight (slightly padded) primitive boxes; the closest hit is
-//          order independent, and ties are resolved with the rank a primitive has in the strict order.
+//  strict: the array is the reference's own tree (Bvh::from, mesh.rs:560-605, handed over in bvh_nodes) with the
+//          reference's padded, origin-including boxes, so Bvh::hit (mesh.rs:608-620) is reproduced test for test,
+//          cull for cull; World / Cube lists are scanned linearly as World::hit does (mesh.rs:66-82).
+//  fast  : binned-SAH trees built here over tight (slightly padded) boxes -- one over the top level, one inside every
+//          Translate / RotateY / ConstantMedium -- whose closest hit is order independent; ties are resolved with
+//          the rank a primitive has in the strict order.
+//
+// Word 7 of an entry doubles as the walk state of a lane standing at it:
+//   0                      box         words 0-5 bounds, word 6 = entry to jump to on a miss
+//   (index << 4) | kind    kind 1 sphere (words 0-6 = c0, dc, r), 2 quad, 3 triangle (planar record index)
+//                          kind 4 transform enter: word 0 = 1 translate (words 1-3 offset) | 2 rotate-y (word 1 sin,
+//                                 word 2 cos); word 4 = enclosing transform-enter entry or NONE
+//                          kind 5 transform leave: word 4 = enclosing transform-enter entry or NONE
+//                          kind 6 medium begin:    word 0 density, word 1 material, word 2 prim id, word 6 = its end
+//                          kind 7 medium end:      word 6 = its begin
+//   ENT_END                terminator appended after the last entry: the walk is complete
+// Links are entry indices while building and byte offsets after finalize().
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -25,12 +37,10 @@
 
 namespace rtx_accel {
 
-enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3 };
-// word 7 of an entry doubles as the walk state of a lane standing at it:
-//   0                      a box            (words 0-5 bounds, word 6 = byte offset of the entry to jump to on a miss)
-//   (index << 4) | kind    a primitive      (kind 1..3)
-//   ENT_END                the terminator appended after the last entry: the walk is complete
+enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3, ENT_XF_PUSH = 4, ENT_XF_POP = 5, ENT_MED_BEGIN = 6, ENT_MED_END = 7 };
 constexpr uint32_t ENT_END = 0xFFFFFFFEu;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int MAX_XF_DEPTH = 3;  // nested Translate / RotateY levels the kernels re-apply when they leave a transform
 
 struct Ent {
     uint32_t w[8];
@@ -39,8 +49,9 @@ static_assert(sizeof(Ent) == 32, "entry must be 32 bytes");
 
 struct Threaded {
     std::vector<Ent> ents;
-    std::vector<uint32_t> rank;  // per entry: tie-break rank of a primitive entry (its first position in the strict order)
+    std::vector<uint32_t> rank;  // per entry: tie-break rank of a primitive / medium entry (first position in the strict order)
     uint32_t n_boxes = 0, n_prims = 0;
+    bool has_brackets = false;   // contains transform or medium entries
 };
 
 static inline uint32_t fbits(float f) {
@@ -75,232 +86,425 @@ static inline Ent prim_entry(const rtx_scene_desc_t& d, uint32_t kind, uint32_t 
     return e;
 }
 
-// -------------------------------------------------------------------------------------------------- strict
-struct StrictBuilder {
-    const rtx_scene_desc_t& d;
-    Threaded& out;
-    std::unordered_map<uint32_t, uint32_t> first_rank;  // prim ref -> first position among primitive tests
-    uint32_t next_rank = 0;
-    std::string err;
-    int depth = 0;
-
-    StrictBuilder(const rtx_scene_desc_t& d_, Threaded& o) : d(d_), out(o) {}
-
-    bool emit(rtx_ref_t r) {
-        if (++depth > 4096) { err = "scene graph too deep (cycle?)"; return false; }
-        uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
-        bool ok = true;
-        switch (k) {
-            case RTX_REF_NODE: {
-                if (i >= d.n_bvh_nodes) { err = "bvh node reference out of range"; ok = false; break; }
-                const rtx_bvh_node_t& n = d.bvh_nodes[i];
-                for (int c = 0; c < 6; c++)
-                    if (n.bounds[c] != n.bounds[c]) { err = "NaN in bvh node bounds"; ok = false; }
-                if (!ok) break;
-                uint32_t at = (uint32_t)out.ents.size();
-                out.ents.push_back(box_entry(n.bounds, 0));
-                out.rank.push_back(0);
-                out.n_boxes++;
-                // a one-element Bvh has left == right (mesh.rs:572-577): the reference tests it twice, so do we
-                ok = emit(n.left) && emit(n.right);
-                out.ents[at].w[6] = (uint32_t)out.ents.size();
-                break;
-            }
-            case RTX_REF_SPHERE:
-            case RTX_REF_QUAD:
-            case RTX_REF_TRI: {
-                uint32_t cnt = k == RTX_REF_SPHERE ? d.n_spheres : (k == RTX_REF_QUAD ? d.n_quads : d.n_tris);
-                if (i >= cnt) { err = "primitive reference out of range"; ok = false; break; }
-                auto it = first_rank.find(r);
-                uint32_t rk = it == first_rank.end() ? (first_rank[r] = next_rank) : it->second;
-                next_rank++;
-                out.ents.push_back(prim_entry(d, k, i));
-                out.rank.push_back(rk);
-                out.n_prims++;
-                break;
-            }
-            case RTX_REF_OBJECT: {
-                if (i >= d.n_objects) { err = "object reference out of range"; ok = false; break; }
-                const rtx_object_t& o = d.objects[i];
-                if (o.kind == RTX_OBJ_LIST) {
-                    // World::hit (mesh.rs:66-82) is a linear scan with a shrinking interval and no box test
-                    if ((uint64_t)o.first + o.count > d.n_refs) { err = "list object exceeds refs"; ok = false; break; }
-                    for (uint32_t c = 0; c < o.count && ok; c++) ok = emit(d.refs[o.first + c]);
-                } else {
-                    err = "Translate / RotateY / ConstantMedium are not implemented by this build";
-                    ok = false;
-                    unsupported = true;
-                }
-                break;
-            }
-            default: err = "unknown reference kind"; ok = false;
-        }
-        depth--;
-        return ok;
-    }
-    bool unsupported = false;
-};
-
-// -------------------------------------------------------------------------------------------------- fast (binned SAH)
-struct PrimBox {
+struct Box3 {
     float lo[3], hi[3];
-    uint32_t ref;   // RTX_REF(kind, index)
-    uint32_t rank;  // tie-break rank
+    void reset() {
+        const float INF = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; a++) { lo[a] = INF; hi[a] = -INF; }
+    }
+    void grow(const Box3& o) {
+        for (int a = 0; a < 3; a++) { lo[a] = std::fmin(lo[a], o.lo[a]); hi[a] = std::fmax(hi[a], o.hi[a]); }
+    }
+    bool valid() const {
+        for (int a = 0; a < 3; a++)
+            if (lo[a] != lo[a] || hi[a] != hi[a]) return false;
+        return true;
+    }
+    float max_abs() const {
+        float m = 0;
+        for (int a = 0; a < 3; a++) m = std::fmax(m, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+        return m;
+    }
 };
 
-static inline void prim_bounds(const rtx_scene_desc_t& d, uint32_t kind, uint32_t i, float lo[3], float hi[3], float coord_range) {
+// Tight bounds of a primitive (spheres over their whole motion).
+static inline Box3 prim_box(const rtx_scene_desc_t& d, uint32_t kind, uint32_t i) {
+    Box3 b;
     if (kind == RTX_REF_SPHERE) {
         const float c0[3] = {d.sph_cx[i], d.sph_cy[i], d.sph_cz[i]};
         const float dc[3] = {d.sph_dx[i], d.sph_dy[i], d.sph_dz[i]};
         float r = std::fabs(d.sph_radius[i]);
         for (int a = 0; a < 3; a++) {
             float c1 = c0[a] + dc[a];  // centre over time in [0,1) sweeps c0 .. c0+dc
-            lo[a] = std::fmin(c0[a], c1) - r;
-            hi[a] = std::fmax(c0[a], c1) + r;
+            b.lo[a] = std::fmin(c0[a], c1) - r;
+            b.hi[a] = std::fmax(c0[a], c1) + r;
         }
     } else if (kind == RTX_REF_QUAD) {
         for (int a = 0; a < 3; a++) {
             float q = d.quad_f[a][i], u = d.quad_f[3 + a][i], v = d.quad_f[6 + a][i];
             float p[4] = {q, q + u, q + v, q + u + v};
-            lo[a] = std::fmin(std::fmin(p[0], p[1]), std::fmin(p[2], p[3]));
-            hi[a] = std::fmax(std::fmax(p[0], p[1]), std::fmax(p[2], p[3]));
+            b.lo[a] = std::fmin(std::fmin(p[0], p[1]), std::fmin(p[2], p[3]));
+            b.hi[a] = std::fmax(std::fmax(p[0], p[1]), std::fmax(p[2], p[3]));
         }
     } else {
         for (int a = 0; a < 3; a++) {
             float p0 = d.tri_f[a][i], p1 = d.tri_f[3 + a][i], p2 = d.tri_f[6 + a][i];
-            lo[a] = std::fmin(p0, std::fmin(p1, p2));
-            hi[a] = std::fmax(p0, std::fmax(p1, p2));
+            b.lo[a] = std::fmin(p0, std::fmin(p1, p2));
+            b.hi[a] = std::fmax(p0, std::fmax(p1, p2));
         }
     }
-    // Outward padding: the slab test and the primitive tests round differently, so a box that is exactly tight could
-    // cull a ray the primitive test would still accept.  1e-3 of the box diagonal plus a few ulps of the coordinates.
+    return b;
+}
+
+// Outward padding of a fast-mode box.  The slab test and the primitive tests round differently, so a box that is
+// exactly tight could cull a ray the primitive test would still accept: 1e-3 of the box diagonal, a few ulps of the
+// coordinates, and the absolute error of the fused box test (~1.2e-7 * (|origin| + |hit point|) <= 2.4e-7 * range).
+static inline void pad_box(Box3& b, float coord_range) {
     float diag2 = 0;
-    for (int a = 0; a < 3; a++) diag2 += (hi[a] - lo[a]) * (hi[a] - lo[a]);
-    float pad = 1e-3f * std::sqrt(diag2);
+    for (int a = 0; a < 3; a++) diag2 += (b.hi[a] - b.lo[a]) * (b.hi[a] - b.lo[a]);
+    float pad = std::isfinite(diag2) ? 1e-3f * std::sqrt(diag2) : 0.0f;
     for (int a = 0; a < 3; a++) {
-        float m = std::fmax(std::fabs(lo[a]), std::fabs(hi[a]));
-        // + the absolute error of the fused box test: ~1.2e-7 * (|origin| + |hit point|) <= 2.4e-7 * coord_range
+        float m = std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
         float p = pad + 4e-7f * m + 3e-7f * coord_range + 1e-30f;
-        lo[a] -= p;
-        hi[a] += p;
+        b.lo[a] -= p;
+        b.hi[a] += p;
     }
 }
 
-struct FastBuilder {
-    std::vector<PrimBox>& prims;
+struct Unit {  // something a fast tree places under a leaf box: a primitive or a whole bracketed object
+    Box3 box;
+    rtx_ref_t ref;
+    uint32_t rank;
+};
+
+class Builder {
+  public:
     const rtx_scene_desc_t& d;
-    Threaded& out;
-    static constexpr int NBINS = 16;
-    uint32_t MAX_LEAF = 4;   // most primitives under one leaf box
-    float C_TRAV = 1.0f;     // cost of a box test in units of a primitive test
+    std::string err;
+    bool unsupported = false;
+    std::unordered_map<uint32_t, uint32_t> first_rank;  // prim / medium ref -> first position among the strict order's tests
+    uint32_t MAX_LEAF = 4;  // most primitives under one leaf box
+    float C_TRAV = 1.0f;    // cost of a box test in units of a primitive test
+    float coord_range = 0;
 
-    FastBuilder(std::vector<PrimBox>& p, const rtx_scene_desc_t& d_, Threaded& o) : prims(p), d(d_), out(o) {}
+    explicit Builder(const rtx_scene_desc_t& d_) : d(d_) {}
 
-    static float half_area(const float lo[3], const float hi[3]) {
-        float e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    bool fail(const char* m, bool unsup = false) {
+        if (err.empty()) err = m;
+        unsupported = unsupported || unsup;
+        return false;
+    }
+
+    // ------------------------------------------------------------------------------------------ shared pieces
+    bool check_ref(rtx_ref_t r) {
+        uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
+        switch (k) {
+            case RTX_REF_NODE: return i < d.n_bvh_nodes || fail("bvh node reference out of range");
+            case RTX_REF_SPHERE: return i < d.n_spheres || fail("sphere reference out of range");
+            case RTX_REF_QUAD: return i < d.n_quads || fail("quad reference out of range");
+            case RTX_REF_TRI: return i < d.n_tris || fail("triangle reference out of range");
+            case RTX_REF_OBJECT: return i < d.n_objects || fail("object reference out of range");
+        }
+        return fail("unknown reference kind");
+    }
+    static bool is_prim(rtx_ref_t r) {
+        uint32_t k = RTX_REF_KIND(r);
+        return k == RTX_REF_SPHERE || k == RTX_REF_QUAD || k == RTX_REF_TRI;
+    }
+
+    void push_prim(Threaded& out, rtx_ref_t r, uint32_t rank) {
+        out.ents.push_back(prim_entry(d, RTX_REF_KIND(r), RTX_REF_INDEX(r)));
+        out.rank.push_back(rank);
+        out.n_prims++;
+    }
+
+    // Emit a Translate / RotateY / ConstantMedium object: opening bracket, its child through `child_fn`, closing bracket.
+    template <class F>
+    bool emit_bracketed(Threaded& out, const rtx_object_t& o, uint32_t obj_index, uint32_t rank, uint32_t enclosing_xf, int xf_depth,
+                        bool in_medium, F child_fn) {
+        out.has_brackets = true;
+        Ent a, b;
+        std::memset(&a, 0, sizeof(a));
+        std::memset(&b, 0, sizeof(b));
+        uint32_t at = (uint32_t)out.ents.size();
+        if (o.kind == RTX_OBJ_MEDIUM) {
+            if (in_medium) return fail("a ConstantMedium inside the boundary of another one is not supported", true);
+            if (o.material >= d.n_materials) return fail("medium material out of range");
+            if (!(o.f[0] == o.f[0])) return fail("NaN medium density");
+            a.w[0] = fbits(o.f[0]);
+            a.w[1] = o.material;
+            a.w[2] = o.prim_id;
+            a.w[7] = ENT_MED_BEGIN | (obj_index << 4);
+            out.ents.push_back(a);
+            out.rank.push_back(rank);
+            if (!child_fn(o.child, enclosing_xf, xf_depth, true)) return false;
+            b.w[6] = at;
+            b.w[7] = ENT_MED_END | (obj_index << 4);
+            out.ents[at].w[6] = (uint32_t)out.ents.size();
+            out.ents.push_back(b);
+            out.rank.push_back(rank);
+            out.n_prims++;
+        } else {
+            if (xf_depth >= MAX_XF_DEPTH) return fail("Translate / RotateY nested deeper than 3 levels", true);
+            a.w[0] = o.kind == RTX_OBJ_TRANSLATE ? 1u : 2u;
+            a.w[1] = fbits(o.f[0]);
+            a.w[2] = fbits(o.f[1]);
+            a.w[3] = fbits(o.f[2]);
+            a.w[4] = enclosing_xf;
+            a.w[7] = ENT_XF_PUSH | (obj_index << 4);
+            out.ents.push_back(a);
+            out.rank.push_back(0);
+            if (!child_fn(o.child, at, xf_depth + 1, in_medium)) return false;
+            b.w[4] = enclosing_xf;
+            b.w[7] = ENT_XF_POP | (obj_index << 4);
+            out.ents[at].w[6] = (uint32_t)out.ents.size();
+            out.ents.push_back(b);
+            out.rank.push_back(0);
+        }
+        return true;
+    }
+
+    // ------------------------------------------------------------------------------------------ strict
+    uint32_t next_rank = 0;
+    int depth = 0;
+    bool emit_strict(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+        if (!check_ref(r)) return false;
+        if (++depth > 4096) return fail("scene graph too deep (cycle?)");
+        uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
+        bool ok = true;
+        if (k == RTX_REF_NODE) {
+            const rtx_bvh_node_t& n = d.bvh_nodes[i];
+            for (int c = 0; c < 6; c++)
+                if (n.bounds[c] != n.bounds[c]) ok = fail("NaN in bvh node bounds");
+            if (ok) {
+                uint32_t at = (uint32_t)out.ents.size();
+                out.ents.push_back(box_entry(n.bounds, 0));
+                out.rank.push_back(0);
+                out.n_boxes++;
+                // a one-element Bvh has left == right (mesh.rs:572-577): the reference tests it twice, so do we
+                ok = emit_strict(out, n.left, enclosing_xf, xf_depth, in_medium) && emit_strict(out, n.right, enclosing_xf, xf_depth, in_medium);
+                out.ents[at].w[6] = (uint32_t)out.ents.size();
+            }
+        } else if (is_prim(r)) {
+            auto it = first_rank.find(r);
+            uint32_t rk = it == first_rank.end() ? (first_rank[r] = next_rank) : it->second;
+            next_rank++;
+            push_prim(out, r, rk);
+        } else {
+            const rtx_object_t& o = d.objects[i];
+            if (o.kind == RTX_OBJ_LIST) {
+                // World::hit (mesh.rs:66-82) is a linear scan with a shrinking interval and no box test
+                if ((uint64_t)o.first + o.count > d.n_refs) ok = fail("list object exceeds refs");
+                for (uint32_t c = 0; c < o.count && ok; c++) ok = emit_strict(out, d.refs[o.first + c], enclosing_xf, xf_depth, in_medium);
+            } else if (o.kind == RTX_OBJ_TRANSLATE || o.kind == RTX_OBJ_ROTATE_Y || o.kind == RTX_OBJ_MEDIUM) {
+                uint32_t rk = 0;
+                if (o.kind == RTX_OBJ_MEDIUM) {
+                    auto it = first_rank.find(r);
+                    rk = it == first_rank.end() ? (first_rank[r] = next_rank) : it->second;
+                    next_rank++;
+                }
+                ok = emit_bracketed(out, o, i, rk, enclosing_xf, xf_depth, in_medium,
+                                    [&](rtx_ref_t c, uint32_t xf, int xd, bool med) { return emit_strict(out, c, xf, xd, med); });
+            } else {
+                ok = fail("unknown object kind");
+            }
+        }
+        depth--;
+        return ok;
+    }
+
+    // ------------------------------------------------------------------------------------------ fast
+    // Local-space bounds of everything under a reference (tight; padding is applied per unit).
+    bool bounds_of(rtx_ref_t r, Box3& out_box, int guard = 0) {
+        if (!check_ref(r)) return false;
+        if (guard > 4096) return fail("scene graph too deep (cycle?)");
+        uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
+        out_box.reset();
+        if (k == RTX_REF_NODE) {
+            Box3 a, b;
+            if (!bounds_of(d.bvh_nodes[i].left, a, guard + 1) || !bounds_of(d.bvh_nodes[i].right, b, guard + 1)) return false;
+            out_box.grow(a);
+            out_box.grow(b);
+        } else if (is_prim(r)) {
+            out_box = prim_box(d, k, i);
+            if (!out_box.valid()) return fail("NaN in primitive bounds");
+        } else {
+            const rtx_object_t& o = d.objects[i];
+            if (o.kind == RTX_OBJ_LIST) {
+                if ((uint64_t)o.first + o.count > d.n_refs) return fail("list object exceeds refs");
+                for (uint32_t c = 0; c < o.count; c++) {
+                    Box3 b;
+                    if (!bounds_of(d.refs[o.first + c], b, guard + 1)) return false;
+                    out_box.grow(b);
+                }
+            } else {
+                Box3 c;
+                if (!bounds_of(o.child, c, guard + 1)) return false;
+                coord_range = std::fmax(coord_range, 2.0f * c.max_abs());
+                if (o.kind == RTX_OBJ_TRANSLATE) {
+                    for (int a = 0; a < 3; a++) { out_box.lo[a] = c.lo[a] + o.f[a]; out_box.hi[a] = c.hi[a] + o.f[a]; }
+                } else if (o.kind == RTX_OBJ_ROTATE_Y) {
+                    // object -> world rotation of the eight corners (mesh.rs:405-423)
+                    const float s = o.f[0], co = o.f[1];
+                    for (int ci = 0; ci < 8; ci++) {
+                        float x = (ci & 1) ? c.hi[0] : c.lo[0], y = (ci & 2) ? c.hi[1] : c.lo[1], z = (ci & 4) ? c.hi[2] : c.lo[2];
+                        float p[3] = {co * x + s * z, y, -s * x + co * z};
+                        for (int a = 0; a < 3; a++) { out_box.lo[a] = std::fmin(out_box.lo[a], p[a]); out_box.hi[a] = std::fmax(out_box.hi[a], p[a]); }
+                    }
+                    float m = out_box.max_abs();
+                    for (int a = 0; a < 3; a++) { out_box.lo[a] -= 1e-6f * m; out_box.hi[a] += 1e-6f * m; }
+                } else if (o.kind == RTX_OBJ_MEDIUM) {
+                    out_box = c;
+                } else {
+                    return fail("unknown object kind");
+                }
+                if (!out_box.valid()) return fail("NaN in object bounds");
+            }
+        }
+        return true;
+    }
+
+    // Units under a reference: BVH nodes and lists are dissolved, primitives and bracketed objects are kept whole.
+    bool collect_units(rtx_ref_t r, std::vector<Unit>& units, int guard = 0) {
+        if (!check_ref(r)) return false;
+        if (guard > 4096) return fail("scene graph too deep (cycle?)");
+        uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
+        if (k == RTX_REF_NODE) {
+            const rtx_bvh_node_t& n = d.bvh_nodes[i];
+            if (!collect_units(n.left, units, guard + 1)) return false;
+            return n.right == n.left || collect_units(n.right, units, guard + 1);
+        }
+        if (k == RTX_REF_OBJECT && d.objects[i].kind == RTX_OBJ_LIST) {
+            const rtx_object_t& o = d.objects[i];
+            if ((uint64_t)o.first + o.count > d.n_refs) return fail("list object exceeds refs");
+            for (uint32_t c = 0; c < o.count; c++)
+                if (!collect_units(d.refs[o.first + c], units, guard + 1)) return false;
+            return true;
+        }
+        Unit u;
+        u.ref = r;
+        auto it = first_rank.find(r);
+        u.rank = it == first_rank.end() ? 0u : it->second;
+        if (!bounds_of(r, u.box)) return false;
+        units.push_back(u);
+        return true;
+    }
+
+    static float half_area(const Box3& b) {
+        float e[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]};
         return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
     }
 
-    void build(uint32_t begin, uint32_t end) {
+    bool emit_fast_subtree(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+        std::vector<Unit> units;
+        if (!collect_units(r, units)) return false;
+        if (units.empty()) return fail("empty subtree");
+        // drop duplicates (a one-element Bvh lists its child twice, shared objects may repeat): keep the first by rank
+        std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.ref != b.ref ? a.ref < b.ref : a.rank < b.rank; });
+        units.erase(std::unique(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.ref == b.ref; }), units.end());
+        std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.rank < b.rank; });
+        for (Unit& u : units) {
+            coord_range_seen = std::fmax(coord_range_seen, u.box.max_abs());
+            pad_box(u.box, coord_range);
+        }
+        return sah(out, units, 0, (uint32_t)units.size(), enclosing_xf, xf_depth, in_medium);
+    }
+    float coord_range_seen = 0;
+
+    bool emit_unit_fast(Threaded& out, const Unit& u, bool guard_box, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+        if (is_prim(u.ref)) {
+            push_prim(out, u.ref, u.rank);
+            return true;
+        }
+        const rtx_object_t& o = d.objects[RTX_REF_INDEX(u.ref)];
+        uint32_t at = NONE;
+        if (guard_box) {  // a bracketed object is a whole subtree: never enter it unless its own box is hit
+            at = (uint32_t)out.ents.size();
+            const float b6[6] = {u.box.lo[0], u.box.hi[0], u.box.lo[1], u.box.hi[1], u.box.lo[2], u.box.hi[2]};
+            out.ents.push_back(box_entry(b6, 0));
+            out.rank.push_back(0);
+            out.n_boxes++;
+        }
+        bool ok = emit_bracketed(out, o, RTX_REF_INDEX(u.ref), u.rank, enclosing_xf, xf_depth, in_medium,
+                                 [&](rtx_ref_t c, uint32_t xf, int xd, bool med) { return emit_fast_subtree(out, c, xf, xd, med); });
+        if (at != NONE) out.ents[at].w[6] = (uint32_t)out.ents.size();
+        return ok;
+    }
+
+    static constexpr int NBINS = 16;
+    bool sah(Threaded& out, std::vector<Unit>& units, uint32_t begin, uint32_t end, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
         const float INF = std::numeric_limits<float>::infinity();
-        float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF}, clo[3] = {INF, INF, INF}, chi[3] = {-INF, -INF, -INF};
-        for (uint32_t i = begin; i < end; i++)
+        Box3 bb, cb;
+        bb.reset();
+        cb.reset();
+        for (uint32_t i = begin; i < end; i++) {
+            bb.grow(units[i].box);
             for (int a = 0; a < 3; a++) {
-                lo[a] = std::fmin(lo[a], prims[i].lo[a]);
-                hi[a] = std::fmax(hi[a], prims[i].hi[a]);
-                float c = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
-                clo[a] = std::fmin(clo[a], c);
-                chi[a] = std::fmax(chi[a], c);
+                float c = 0.5f * (units[i].box.lo[a] + units[i].box.hi[a]);
+                cb.lo[a] = std::fmin(cb.lo[a], c);
+                cb.hi[a] = std::fmax(cb.hi[a], c);
             }
-        uint32_t n = end - begin;
-        uint32_t at = (uint32_t)out.ents.size();
-        const float b6[6] = {lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]};
+        }
+        const uint32_t n = end - begin;
+        const uint32_t at = (uint32_t)out.ents.size();
+        const float b6[6] = {bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1], bb.lo[2], bb.hi[2]};
         out.ents.push_back(box_entry(b6, 0));
         out.rank.push_back(0);
         out.n_boxes++;
 
-        // choose a split: binned SAH over the centroid bounds
-        int best_axis = -1;
-        int best_bin = -1;
+        int best_axis = -1, best_bin = -1;
         float best_cost = INF;
-        const float parent_area = half_area(lo, hi);
+        const float parent_area = half_area(bb);
         if (n > 1) {
             for (int a = 0; a < 3; a++) {
-                float ext = chi[a] - clo[a];
-                if (!(ext > 0)) continue;
+                float ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0) || !std::isfinite(ext)) continue;
                 uint32_t cnt[NBINS] = {0};
-                float blo[NBINS][3], bhi[NBINS][3];
-                for (int b = 0; b < NBINS; b++)
-                    for (int k = 0; k < 3; k++) { blo[b][k] = INF; bhi[b][k] = -INF; }
+                Box3 bins[NBINS];
+                for (int b = 0; b < NBINS; b++) bins[b].reset();
                 float scale = (float)NBINS / ext;
                 for (uint32_t i = begin; i < end; i++) {
-                    float c = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
-                    int b = std::min(NBINS - 1, std::max(0, (int)((c - clo[a]) * scale)));
+                    float c = 0.5f * (units[i].box.lo[a] + units[i].box.hi[a]);
+                    int b = std::min(NBINS - 1, std::max(0, (int)((c - cb.lo[a]) * scale)));
                     cnt[b]++;
-                    for (int k = 0; k < 3; k++) {
-                        blo[b][k] = std::fmin(blo[b][k], prims[i].lo[k]);
-                        bhi[b][k] = std::fmax(bhi[b][k], prims[i].hi[k]);
-                    }
+                    bins[b].grow(units[i].box);
                 }
                 float rarea[NBINS];
                 uint32_t rcnt[NBINS];
-                float rl[3] = {INF, INF, INF}, rh[3] = {-INF, -INF, -INF};
+                Box3 acc;
+                acc.reset();
                 uint32_t rc = 0;
                 for (int b = NBINS - 1; b > 0; b--) {
-                    for (int k = 0; k < 3; k++) { rl[k] = std::fmin(rl[k], blo[b][k]); rh[k] = std::fmax(rh[k], bhi[b][k]); }
+                    if (cnt[b]) acc.grow(bins[b]);
                     rc += cnt[b];
-                    rarea[b] = rc ? half_area(rl, rh) : 0;
+                    rarea[b] = rc ? half_area(acc) : 0;
                     rcnt[b] = rc;
                 }
-                float ll[3] = {INF, INF, INF}, lh[3] = {-INF, -INF, -INF};
+                acc.reset();
                 uint32_t lc = 0;
                 for (int b = 0; b < NBINS - 1; b++) {
-                    for (int k = 0; k < 3; k++) { ll[k] = std::fmin(ll[k], blo[b][k]); lh[k] = std::fmax(lh[k], bhi[b][k]); }
+                    if (cnt[b]) acc.grow(bins[b]);
                     lc += cnt[b];
                     if (lc == 0 || rcnt[b + 1] == 0) continue;
-                    float cost = half_area(ll, lh) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
+                    float cost = half_area(acc) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
                     if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
                 }
             }
         }
-        // SAH: one box test costs about as much as a primitive test here, so compare (1 + split) against n
-        bool make_leaf = n <= 1 || best_axis < 0 ||
-                         (n <= MAX_LEAF && !(parent_area > 0 && C_TRAV + best_cost / parent_area < (float)n));
+        // SAH: one box test costs about as much as a primitive test here, so compare (C_TRAV + split) against n
+        bool make_leaf = n <= 1 || best_axis < 0 || (n <= MAX_LEAF && !(parent_area > 0 && C_TRAV + best_cost / parent_area < (float)n));
+        bool ok = true;
         if (make_leaf && n > MAX_LEAF) {
-            // all centroids coincide: split the range in half to bound the leaf size
-            uint32_t mid = begin + n / 2;
-            build(begin, mid);
-            build(mid, end);
+            uint32_t mid = begin + n / 2;  // all centroids coincide: halve the range to bound the leaf size
+            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium) && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
         } else if (make_leaf) {
-            std::sort(prims.begin() + begin, prims.begin() + end, [](const PrimBox& x, const PrimBox& y) { return x.rank < y.rank; });
-            for (uint32_t i = begin; i < end; i++) {
-                out.ents.push_back(prim_entry(d, RTX_REF_KIND(prims[i].ref), RTX_REF_INDEX(prims[i].ref)));
-                out.rank.push_back(prims[i].rank);
-                out.n_prims++;
-            }
+            std::sort(units.begin() + begin, units.begin() + end, [](const Unit& x, const Unit& y) { return x.rank < y.rank; });
+            for (uint32_t i = begin; i < end && ok; i++) ok = emit_unit_fast(out, units[i], n > 1, enclosing_xf, xf_depth, in_medium);
         } else {
-            float ext = chi[best_axis] - clo[best_axis];
-            float scale = (float)NBINS / ext;
-            int a = best_axis;
-            float base = clo[a];
-            auto midit = std::partition(prims.begin() + begin, prims.begin() + end, [&](const PrimBox& p) {
-                float c = 0.5f * (p.lo[a] + p.hi[a]);
+            const int a = best_axis;
+            const float base = cb.lo[a], scale = (float)NBINS / (cb.hi[a] - cb.lo[a]);
+            auto midit = std::partition(units.begin() + begin, units.begin() + end, [&](const Unit& p) {
+                float c = 0.5f * (p.box.lo[a] + p.box.hi[a]);
                 int b = std::min(NBINS - 1, std::max(0, (int)((c - base) * scale)));
                 return b <= best_bin;
             });
-            uint32_t mid = (uint32_t)(midit - prims.begin());
+            uint32_t mid = (uint32_t)(midit - units.begin());
             if (mid == begin || mid == end) mid = begin + n / 2;
-            build(begin, mid);
-            build(mid, end);
+            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium) && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
         }
         out.ents[at].w[6] = (uint32_t)out.ents.size();
+        return ok;
     }
 };
 
 // Turn entry indices into byte offsets and append the terminator.
 static inline void finalize(Threaded& t) {
-    for (Ent& e : t.ents)
-        if (e.w[7] == ENT_BOX) e.w[6] *= (uint32_t)sizeof(Ent);
+    const uint32_t S = (uint32_t)sizeof(Ent);
+    for (Ent& e : t.ents) {
+        uint32_t kind = e.w[7] == ENT_BOX ? ENT_BOX : (e.w[7] & 15u);
+        if (kind == ENT_BOX || kind == ENT_MED_BEGIN || kind == ENT_MED_END || kind == ENT_XF_PUSH) e.w[6] *= S;
+        if ((kind == ENT_XF_PUSH || kind == ENT_XF_POP) && e.w[4] != NONE) e.w[4] *= S;
+    }
     Ent end;
     std::memset(&end, 0, sizeof(end));
     end.w[7] = ENT_END;
@@ -310,36 +514,29 @@ static inline void finalize(Threaded& t) {
 
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.
 static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, float& coord_range, std::string& err) {
-    StrictBuilder sb(d, strict);
-    if (!sb.emit(d.root)) {
-        err = sb.err;
-        return sb.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
+    Builder b(d);
+    if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) b.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RTX_SAH_CTRAV")) b.C_TRAV = (float)std::atof(e);
+    if (!b.emit_strict(strict, d.root, NONE, 0, false)) {
+        err = b.err;
+        return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
     }
     if (strict.n_prims == 0) { err = "empty scene: no primitive is reachable from the root"; return RTX_ERR_INVALID; }
-    std::vector<PrimBox> prims;
-    prims.reserve(sb.first_rank.size());
-    // coordinate range of the scene: every ray the render kernels trace starts at the camera or on a primitive
-    coord_range = 0.0f;
-    for (auto& kv : sb.first_rank) {
-        float lo[3], hi[3];
-        prim_bounds(d, RTX_REF_KIND(kv.first), RTX_REF_INDEX(kv.first), lo, hi, 0.0f);
-        for (int a = 0; a < 3; a++) {
-            if (lo[a] != lo[a] || hi[a] != hi[a]) { err = "NaN in primitive bounds"; return RTX_ERR_INVALID; }
-            coord_range = std::fmax(coord_range, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
-        }
+    // coordinate range of the scene: every ray the render kernels trace starts at the camera or on a primitive, in
+    // world space or in the local space of a transform (bounds_of doubles the local ranges it meets)
+    Box3 world;
+    b.coord_range = 0.0f;
+    if (!b.bounds_of(d.root, world)) {
+        err = b.err;
+        return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
     }
-    for (auto& kv : sb.first_rank) {
-        PrimBox p;
-        p.ref = kv.first;
-        p.rank = kv.second;
-        prim_bounds(d, RTX_REF_KIND(kv.first), RTX_REF_INDEX(kv.first), p.lo, p.hi, coord_range);
-        prims.push_back(p);
+    b.coord_range = std::fmax(b.coord_range, world.max_abs());
+    if (!std::isfinite(b.coord_range)) { err = "non-finite scene bounds"; return RTX_ERR_INVALID; }
+    if (!b.emit_fast_subtree(fast, d.root, NONE, 0, false)) {
+        err = b.err;
+        return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
     }
-    std::sort(prims.begin(), prims.end(), [](const PrimBox& x, const PrimBox& y) { return x.rank < y.rank; });
-    FastBuilder fb(prims, d, fast);
-    if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) fb.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RTX_SAH_CTRAV")) fb.C_TRAV = (float)std::atof(e);
-    fb.build(0, (uint32_t)prims.size());
+    coord_range = b.coord_range;
     if (strict.ents.size() >= (1u << 26) || fast.ents.size() >= (1u << 26)) { err = "scene too large for 32-bit entry offsets"; return RTX_ERR_INVALID; }
     finalize(strict);
     finalize(fast);

@@ -159,6 +159,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     std::string err;
     int rc = rtx_accel::build(*d, strict, fast, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
+    if (strict.has_brackets) s->full_features = true;  // transforms / media need the bracket-aware kernel variant
 
     HIP_TRY(hipGetDevice(&s->device));
     hipDeviceProp_t prop;
@@ -288,26 +289,39 @@ extern "C" int rtx_scene_create(const rtx_scene_desc_t* desc, rtx_scene_t** out)
 
 // ================================================================================================ trace
 template <bool STRICT>
-__global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
+__global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax, uint64_t seed,
                                                     rtx_hit_t* __restrict__ hits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
+    constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_ROBUST;
     const uint4* __restrict__ ents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
-    Ray r;
-    r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
-    r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
-    r.time = rays[i].time;
-    const RayConst rc = ray_const<STRICT ? SLAB_STRICT : SLAB_ROBUST>(r);
+    const EntReader reader{ents};
+    Ray wray;
+    wray.ox = rays[i].o[0]; wray.oy = rays[i].o[1]; wray.oz = rays[i].o[2];
+    wray.dx = rays[i].d[0]; wray.dy = rays[i].d[1]; wray.dz = rays[i].d[2];
+    wray.time = rays[i].time;
+    Ray r = wray;
+    RayConst rc = ray_const<SLAB>(r);
+    Rng rng = rng_init(seed, (uint32_t)i, 0u);  // only a ConstantMedium draws from it (mesh.rs:659)
+    WalkX x;
+    walkx_init(x, tmin);
     Best best;
     best.t = tmax;
     best.ent = NO_HIT;
     uint32_t off = 0;
     for (;;) {
-        const uint4 ea = ents[off / 16], eb = ents[off / 16 + 1];
+        uint4 ea, eb;
+        reader.load(off, ea, eb);
         if (eb.w == ENT_END) break;
-        off = walk_step<STRICT>(S, ea, eb, off, r, rc, tmin, best, rank);
+        if (eb.w != ENT_BOX && (eb.w & 15u) >= ENT_XF_PUSH) {
+            bracket_step<STRICT, SLAB>(reader, ea, eb, off, r, rc, wray, best, x, tmin, rng, rank);
+        } else {
+            const uint32_t at = off;
+            off = walk_step<STRICT>(S, ea, eb, off, r, rc, x.tmin, best, rank);
+            if (best.ent == at) x.best_xf = x.cur_xf;
+        }
     }
     rtx_hit_t out;
     if (best.ent == NO_HIT) {
@@ -318,8 +332,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
         out.front_face = 0;
         out.p[0] = out.p[1] = out.p[2] = 0.0f;
     } else {
-        const uint4 ea = ents[best.ent / 16], eb = ents[best.ent / 16 + 1];
-        HitRec h = make_hit<true>(S, ea, eb, r, best.t);
+        HitRec h = make_hit_x<true, true>(S, reader, wray, best, x.best_xf);
         out.prim_id = h.prim_id;
         out.t = best.t;
         out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
@@ -339,9 +352,9 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
     if (opts->traversal == RTX_TRAVERSAL_STRICT)
-        hipLaunchKernelGGL(trace_kernel<true>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+        hipLaunchKernelGGL(trace_kernel<true>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, opts->seed, hits_dev);
     else
-        hipLaunchKernelGGL(trace_kernel<false>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+        hipLaunchKernelGGL(trace_kernel<false>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, opts->seed, hits_dev);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
 }
@@ -441,6 +454,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     float br = 0, bg = 0, bb = 0;  // path throughput
     uint32_t slot = 0, depth_left = 0;
     Rng rng{};
+    // FULL only: the caller's (world) ray and the bracket state of the walk (transforms, media)
+    Ray wray{};
+    WalkX wx{};
+    const EntReader reader{ENTS_IN_LDS ? reinterpret_cast<const uint4*>(smem) : gents};
 
 #define RTX_LOAD_ENTRY(o, a, b)                                                \
     do {                                                                       \
@@ -459,6 +476,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
         rc = ray_const<SLAB>(ray);       \
         best.t = __builtin_inff();       \
         best.ent = NO_HIT;               \
+        if (FULL) {                      \
+            wray = ray;                  \
+            walkx_init(wx, tmin);         \
+        }                                \
         rays_traced++;                   \
         off = 0;                         \
         RTX_LOAD_ENTRY(off, ea, eb);     \
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                     sc[1] += __popcll(__ballot(eb.w == ENT_BOX));
 #endif
                     if (eb.w == ENT_BOX) {
-                        const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, tmin, best.t);
+                        const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, FULL ? wx.tmin : tmin, best.t);
                         off = hit ? off + ENT_BYTES : eb.z;
                         RTX_LOAD_ENTRY(off, ea, eb);
                     }
@@ -521,14 +542,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
 #endif
                 if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
                     const uint32_t kind = eb.w & 15u;
-                    if (kind == ENT_SPHERE) {
-                        sphere_test<STRICT>(ea, eb, ray, rc, tmin, best, off, rank);
+                    const float lane_tmin = FULL ? wx.tmin : tmin;
+                    if (FULL && kind >= ENT_XF_PUSH) {
+                        // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
+                        bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
                     } else {
-                        const uint32_t pi = eb.w >> 4;
-                        const bool tri = kind == ENT_TRI;
-                        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, tmin, best, off, rank);
+                        if (kind == ENT_SPHERE) {
+                            sphere_test<STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);
+                        } else {
+                            const uint32_t pi = eb.w >> 4;
+                            const bool tri = kind == ENT_TRI;
+                            planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                        }
+                        if (FULL && best.ent == off) wx.best_xf = wx.cur_xf;
+                        off += ENT_BYTES;
                     }
-                    off += ENT_BYTES;
                     RTX_LOAD_ENTRY(off, ea, eb);
                 }
             } else {
@@ -545,17 +573,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                         atomicAdd(&acc[slot * 3 + 1], bg * C.background[1]);
                         atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
                     } else {
-                        uint4 ha, hb;
-                        RTX_LOAD_ENTRY(best.ent, ha, hb);
                         HitRec h;
                         if (FULL) {
+                            uint4 ha, hb;
+                            RTX_LOAD_ENTRY(best.ent, ha, hb);
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
                             const uint32_t kind = hb.w & 15u;
-                            const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
-                                                                    : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
-                            const bool want_uv = (S.mats[mat].w & 1u) != 0u;
-                            h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
+                            bool want_uv = false;
+                            if (kind <= ENT_TRI) {
+                                const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
+                                                                        : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
+                                want_uv = (S.mats[mat].w & 1u) != 0u;
+                            }
+                            h = want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
                         } else {
+                            uint4 ha, hb;
+                            RTX_LOAD_ENTRY(best.ent, ha, hb);
                             h = make_hit<false, false>(S, ha, hb, ray, best.t);
                         }
                         ScatterOut so = shade<FULL>(S, ray, h, rng);

@@ -10,7 +10,8 @@
 
 namespace rtxd {
 
-enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3 };
+enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3, ENT_XF_PUSH = 4, ENT_XF_POP = 5, ENT_MED_BEGIN = 6, ENT_MED_END = 7 };
+constexpr uint32_t XF_NONE = 0xFFFFFFFFu;
 // Word 7 of the entry a lane stands at is also that lane's walk state (see accel.hpp): 0 = box, ENT_END = walk
 // complete, anything else = primitive.  ST_IDLE marks a lane without a path.
 constexpr uint32_t ENT_END = 0xFFFFFFFEu;
@@ -322,6 +323,189 @@ __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, c
     h.nx = front ? nx : -nx;
     h.ny = front ? ny : -ny;
     h.nz = front ? nz : -nz;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------- brackets
+// Translate / RotateY / ConstantMedium (mesh.rs:324-432, :627-696) appear in the threaded array as bracket entries
+// around their child's entries.  Extra per-ray walk state they need:
+struct WalkX {
+    uint32_t cur_xf;   // innermost transform-enter entry the walk is inside, XF_NONE at top level
+    uint32_t best_xf;  // cur_xf at the moment the current best hit was accepted
+    float tmin;        // current interval start (differs from the caller's inside a medium's boundary queries)
+    float sv_t;        // while inside a medium: the caller's best so far ...
+    uint32_t sv_ent, sv_xf;
+    float med_t1;      // NaN during the first boundary query, hit1.distance during the second
+};
+__device__ __forceinline__ void walkx_init(WalkX& x, float tmin) {
+    x.cur_xf = XF_NONE;
+    x.best_xf = XF_NONE;
+    x.tmin = tmin;
+    x.sv_t = 0.0f;
+    x.sv_ent = NO_HIT;
+    x.sv_xf = XF_NONE;
+    x.med_t1 = __builtin_nanf("");
+}
+
+struct EntReader {  // reads entries through a generic pointer (LDS or global); used on the rare bracket paths
+    const uint4* base;
+    __device__ __forceinline__ void load(uint32_t off, uint4& a, uint4& b) const {
+        const char* p = reinterpret_cast<const char*>(base) + off;
+        a = *reinterpret_cast<const uint4*>(p);
+        b = *reinterpret_cast<const uint4*>(p + 16);
+    }
+};
+
+// Translate::hit (mesh.rs:332) / RotateY::hit (mesh.rs:365-372): the ray handed to the wrapped object
+__device__ __forceinline__ void xf_apply(const uint4& ea, Ray& r) {
+    if (ea.x == 1u) {
+        r.ox = r.ox - as_f(ea.y);
+        r.oy = r.oy - as_f(ea.z);
+        r.oz = r.oz - as_f(ea.w);
+    } else {
+        const float s = as_f(ea.y), c = as_f(ea.z);
+        const float ox = c * r.ox - s * r.oz, oz = s * r.ox + c * r.oz;
+        const float dx = c * r.dx - s * r.dz, dz = s * r.dx + c * r.dz;
+        r.ox = ox;
+        r.oz = oz;
+        r.dx = dx;
+        r.dz = dz;
+    }
+}
+// The ray as seen inside transform-enter entry `xf` (and all transforms enclosing it), derived from the world ray.
+__device__ inline Ray xf_chain_ray(const EntReader& ents, uint32_t xf, const Ray& w) {
+    uint32_t x0 = xf, x1 = XF_NONE, x2 = XF_NONE;
+    uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0, a2 = a0, b2 = a0;
+    if (x0 != XF_NONE) {
+        ents.load(x0, a0, b0);
+        x1 = b0.x;
+    }
+    if (x1 != XF_NONE) {
+        ents.load(x1, a1, b1);
+        x2 = b1.x;
+    }
+    if (x2 != XF_NONE) ents.load(x2, a2, b2);
+    Ray r = w;
+    if (x2 != XF_NONE) xf_apply(a2, r);
+    if (x1 != XF_NONE) xf_apply(a1, r);
+    if (x0 != XF_NONE) xf_apply(a0, r);
+    return r;
+}
+
+// One walk step at a bracket entry (ea, eb) at byte offset off.  `ray` is the ray in the current frame, `wray` the
+// caller's ray; `main_tmin` the start of the caller's interval; the caller's interval end is the running best.
+template <bool STRICT, int SLAB>
+__device__ inline void bracket_step(const EntReader& ents, const uint4& ea, const uint4& eb, uint32_t& off, Ray& ray, RayConst& rc, const Ray& wray,
+                                    Best& best, WalkX& x, float main_tmin, Rng& rng, const uint32_t* __restrict__ rank) {
+    const uint32_t kind = eb.w & 15u;
+    if (kind == ENT_XF_PUSH) {
+        x.cur_xf = off;
+        xf_apply(ea, ray);
+        rc = ray_const<SLAB>(ray);
+        off += ENT_BYTES;
+    } else if (kind == ENT_XF_POP) {
+        x.cur_xf = eb.x;
+        ray = xf_chain_ray(ents, x.cur_xf, wray);
+        rc = ray_const<SLAB>(ray);
+        off += ENT_BYTES;
+    } else if (kind == ENT_MED_BEGIN) {
+        // ConstantMedium::hit (mesh.rs:634-638): first boundary query over the whole line
+        x.sv_t = best.t;
+        x.sv_ent = best.ent;
+        x.sv_xf = x.best_xf;
+        best.t = __builtin_inff();
+        best.ent = NO_HIT;
+        x.tmin = -__builtin_inff();
+        x.med_t1 = __builtin_nanf("");
+        off += ENT_BYTES;
+    } else {  // ENT_MED_END
+        if (x.med_t1 != x.med_t1 && best.ent != NO_HIT) {
+            // second boundary query, from just behind the first hit (mesh.rs:636-638)
+            x.med_t1 = best.t;
+            x.tmin = best.t + 0.0001f;
+            best.t = __builtin_inff();
+            best.ent = NO_HIT;
+            off = eb.z + ENT_BYTES;
+        } else {
+            bool some = false;
+            float distance = 0.0f;
+            if (x.med_t1 == x.med_t1 && best.ent != NO_HIT) {  // both boundary hits exist (mesh.rs:640-665)
+                float t1 = x.med_t1, t2 = best.t;
+                if (t1 < main_tmin) t1 = main_tmin;
+                if (t2 > x.sv_t) t2 = x.sv_t;
+                if (!(t1 >= t2)) {
+                    if (t1 < 0.0f) t1 = 0.0f;
+                    uint4 ba, bb;
+                    ents.load(eb.z, ba, bb);
+                    const float ray_length = __builtin_sqrtf(dot3(ray.dx, ray.dy, ray.dz, ray.dx, ray.dy, ray.dz));
+                    const float inside = (t2 - t1) * ray_length;
+                    const float density = -1.0f / as_f(ba.x);
+                    const float hit_distance = density * logf(rng_f32(rng));
+                    if (!(hit_distance > inside)) {
+                        distance = t1 + hit_distance / ray_length;
+                        some = true;
+                    }
+                }
+            }
+            best.t = x.sv_t;
+            best.ent = x.sv_ent;
+            x.best_xf = x.sv_xf;
+            x.tmin = main_tmin;
+            x.med_t1 = __builtin_nanf("");
+            // strict: the caller takes whatever the medium returns (mesh.rs:76-78, :611-616); fast: closest hit, reference tie order
+            if (some && (STRICT || in_range<false>(distance, main_tmin, best, off, rank))) {
+                best.t = distance;
+                best.ent = off;
+                x.best_xf = x.cur_xf;
+            }
+            off += ENT_BYTES;
+        }
+    }
+}
+
+// Hit record of the accepted entry at best.ent when the scene has brackets: evaluate it with the ray of its own
+// frame, then carry point and normal out through the enclosing transforms as the reference does -- Translate adds its
+// offset to the point (mesh.rs:334); RotateY re-applies its FORWARD rotation and reads the already overwritten x
+// (mesh.rs:378-382).
+template <bool WANT_UV, bool EXACT>
+__device__ inline HitRec make_hit_x(const DevScene& S, const EntReader& ents, const Ray& wray, const Best& best, uint32_t best_xf) {
+    uint4 ha, hb;
+    ents.load(best.ent, ha, hb);
+    const Ray lr = xf_chain_ray(ents, best_xf, wray);
+    HitRec h;
+    if ((hb.w & 15u) == ENT_MED_END) {  // mesh.rs:667-674
+        uint4 ba, bb;
+        ents.load(hb.z, ba, bb);
+        h.px = lr.ox + lr.dx * best.t;
+        h.py = lr.oy + lr.dy * best.t;
+        h.pz = lr.oz + lr.dz * best.t;
+        h.nx = 1.0f;
+        h.ny = 0.0f;
+        h.nz = 0.0f;
+        h.u = 0.0f;
+        h.v = 0.0f;
+        h.mat = ba.y;
+        h.prim_id = ba.z;
+    } else {
+        h = make_hit<WANT_UV, EXACT>(S, ha, hb, lr, best.t);
+    }
+    uint32_t xf = best_xf;
+    for (int level = 0; level < 3 && xf != XF_NONE; level++) {
+        uint4 a, b;
+        ents.load(xf, a, b);
+        if (a.x == 1u) {
+            h.px += as_f(a.y);
+            h.py += as_f(a.z);
+            h.pz += as_f(a.w);
+        } else {
+            const float s = as_f(a.y), c = as_f(a.z);
+            h.px = c * h.px - s * h.pz;
+            h.pz = s * h.px + c * h.pz;
+            h.nx = c * h.nx - s * h.nz;
+            h.nz = s * h.nx + c * h.nz;
+        }
+        xf = b.x;
+    }
     return h;
 }
 
