@@ -152,7 +152,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.scene} seed {args.seed} (book-1 random spheres, ~485 spheres, mixed materials), "
+            "config": {"workload": f"{args.scene} seed {args.seed} ({scene.n_prims} primitives), "
                                    f"{cfg.width}x{cfg.height}, {args.spp} spp, depth {args.depth}",
                        "traversal": args.traversal, "russian_roulette_start": args.rr,
                        "parallelism": f"spp-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
