@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--traversal", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--split", choices=["spp", "tile"], default="spp", help="multi-GPU partition: sample ranges or interleaved 8x8 tiles")
     ap.add_argument("--rr", type=int, default=0, help="Russian roulette start depth (0 = off, as in the reference)")
     ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -96,14 +97,17 @@ def main():
     accum = torch.zeros(n3, device="cuda", dtype=torch.float32)
     rgb = torch.zeros(n3, device="cuda", dtype=torch.uint8)
     stream = torch.cuda.current_stream().cuda_stream
-    begin, end = parallel.sample_range(args.spp, rank, world)
+    if args.split == "tile":
+        begin, end, tile_rank, tile_world = 0, args.spp, rank, world
+    else:
+        (begin, end), tile_rank, tile_world = parallel.sample_range(args.spp, rank, world), 0, 1
     kernel_ms, rays = [], []
 
     def step(record):
         accum.zero_()
         st = render.Stats()
         cam.render_accumulate(scene, accum.data_ptr(), begin, end, seed=args.seed, traversal=trav, rr_start_depth=args.rr,
-                              stream=stream, stats=st)
+                              stream=stream, stats=st, tile_rank=tile_rank, tile_world=tile_world)
         if world > 1:
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
@@ -155,7 +159,7 @@ def main():
             "config": {"workload": f"{args.scene} seed {args.seed} ({scene.n_prims} primitives), "
                                    f"{cfg.width}x{cfg.height}, {args.spp} spp, depth {args.depth}",
                        "traversal": args.traversal, "russian_roulette_start": args.rr,
-                       "parallelism": f"spp-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
+                       "parallelism": f"{args.split}-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 1),
             "rays_per_sample": round(total_rays / (samples_per_step * args.steps), 3),
         }

@@ -211,7 +211,10 @@ typedef struct rtx_render_opts {
     uint32_t sample_begin, sample_end; /* sample index range to render; 0,0 = all of 0..samples_per_pixel */
     uint32_t traversal;                /* RTX_TRAVERSAL_* */
     uint32_t rr_start_depth;           /* Russian roulette from this bounce on; 0 = off (the reference has none) */
-    uint32_t reserved[4];
+    uint32_t tile_rank, tile_world;    /* tile split: render only the 8x8 pixel tiles t with t % tile_world == tile_rank
+                                          (row-major tile index); tile_world 0 or 1 = all tiles.  Other pixels of
+                                          accum_dev are left untouched, so per-rank buffers add up to the frame. */
+    uint32_t reserved[2];
 } rtx_render_opts_t;
 
 typedef struct rtx_stats {

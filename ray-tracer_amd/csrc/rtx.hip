@@ -396,6 +396,7 @@ struct RenderParams {
     uint32_t batch;       // samples per item
     uint32_t n_batches;
     uint32_t tiles_x, tiles_y;
+    uint32_t tile_rank, tile_world, n_owned;  // this call renders tiles tile_rank, tile_rank + tile_world, ... (n_owned of them)
     uint32_t n_items;
     uint32_t rr_start;
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
@@ -438,7 +439,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     }
 
     const rtx_camera_t& C = P.cam;
-    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     unsigned long long rays_traced = 0;
 #ifdef RTX_STAGE_COUNTERS
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
         if (lane == 0) item = atomicAdd(P.item_counter, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= P.n_items) break;
-        const uint32_t tile = item % n_tiles, batch = item / n_tiles;
+        const uint32_t tile = P.tile_rank + (item % P.n_owned) * P.tile_world, batch = item / P.n_owned;
         const uint32_t tx = (tile % P.tiles_x) * TILE, ty = (tile / P.tiles_x) * TILE;
         const uint32_t vw = min((uint32_t)TILE, C.width - tx), vh = min((uint32_t)TILE, C.height - ty);
         const uint32_t s0 = P.sample_begin + batch * P.batch;
@@ -685,9 +685,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
 #endif
 }
 
-__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ partial, uint32_t n_batches, size_t n, float* __restrict__ accum) {
+__global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ partial, uint32_t n_batches, size_t n, float* __restrict__ accum, uint32_t width,
+                                                     uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (tile_world > 1u) {  // pixels of tiles another rank owns were not rendered by this call
+        const uint32_t pix = (uint32_t)(i / 3), px = pix % width, py = pix / width;
+        const uint32_t tile = (py / TILE) * tiles_x + px / TILE;
+        if (tile % tile_world != tile_rank) return;
+    }
     float s = accum[i];
     for (uint32_t b = 0; b < n_batches; b++) s += partial[(size_t)b * n + i];
     accum[i] = s;
@@ -755,7 +761,12 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     n_batches = std::min<uint32_t>(n_batches, env_u32("RTX_MAX_BATCHES", 64));
     P.batch = (spp + n_batches - 1) / n_batches;
     P.n_batches = (spp + P.batch - 1) / P.batch;
-    P.n_items = n_tiles * P.n_batches;
+    P.tile_world = std::max<uint32_t>(1u, opts->tile_world);
+    P.tile_rank = opts->tile_rank;
+    if (P.tile_rank >= P.tile_world) return fail(RTX_ERR_INVALID, "tile_rank >= tile_world");
+    P.n_owned = n_tiles > P.tile_rank ? (n_tiles - P.tile_rank + P.tile_world - 1) / P.tile_world : 0u;
+    P.n_items = P.n_owned * P.n_batches;
+    if (P.n_items == 0) return RTX_OK;
     P.rr_start = opts->rr_start_depth;
     P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
     P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 12));
@@ -800,7 +811,8 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     HIP_TRY(hipEventRecord(scene->ev1, st));
     {
         dim3 rb(256), rg((unsigned)((npix3 + 255) / 256));
-        hipLaunchKernelGGL(reduce_kernel, rg, rb, 0, st, (const float*)scene->partial, P.n_batches, npix3, accum_dev);
+        hipLaunchKernelGGL(reduce_kernel, rg, rb, 0, st, (const float*)scene->partial, P.n_batches, npix3, accum_dev, cam->width, P.tiles_x, P.tile_rank,
+                           P.tile_world);
         HIP_TRY(hipGetLastError());
     }
     if (stats) {

@@ -50,7 +50,7 @@ class RenderOpts(C.Structure):
     """rtx_render_opts_t"""
 
     _fields_ = [("seed", C.c_uint64), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("traversal", C.c_uint32),
-                ("rr_start_depth", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("rr_start_depth", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class Stats(C.Structure):
@@ -270,9 +270,10 @@ class Camera:
         return out[0] if len(out) == 1 else tuple(out)
 
     def render_accumulate(self, scene, accum_ptr, sample_begin, sample_end, seed=0, traversal=TRAVERSAL_FAST, rr_start_depth=0,
-                          stream=None, stats=None):
-        """rtx_render_accumulate on a device buffer (3*W*H f32) for the sample range [sample_begin, sample_end)."""
-        opts = RenderOpts(seed, sample_begin, sample_end, traversal, rr_start_depth)
+                          stream=None, stats=None, tile_rank=0, tile_world=1):
+        """rtx_render_accumulate on a device buffer (3*W*H f32) for the sample range [sample_begin, sample_end) of the
+        tiles t with t % tile_world == tile_rank."""
+        opts = RenderOpts(seed, sample_begin, sample_end, traversal, rr_start_depth, tile_rank, tile_world)
         _check(rtx().rtx_render_accumulate(scene.device, C.byref(self.ffi), C.byref(opts), accum_ptr, stream,
                                            C.byref(stats) if stats is not None else None))
 

@@ -214,6 +214,30 @@ def test_sample_ranges_add_up_and_runs_repeat(render, scenes):
     assert float(full.min()) > -1e3 and bool(torch.isfinite(full).all())
 
 
+def test_tile_split_adds_up_exactly(render, scenes):
+    """Interleaved 8x8 tiles over three virtual ranks: every pixel is rendered by exactly one rank with the same batches
+    as the whole-frame call, so the summed buffers equal the single-rank frame bit for bit."""
+    import torch
+
+    cfg, bvh = scenes.make("default", seed=0, width=203, height=117, samples_per_pixel=8)
+    scene, cam = render.Scene(bvh), render.Camera(cfg)
+    n = cfg.width * cfg.height * 3
+    st = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros(n, device="cuda")
+    cam.render_accumulate(scene, full.data_ptr(), 0, 8, seed=2, stream=st)
+    parts = []
+    for r in range(3):
+        buf = torch.zeros(n, device="cuda")
+        cam.render_accumulate(scene, buf.data_ptr(), 0, 8, seed=2, stream=st, tile_rank=r, tile_world=3)
+        parts.append(buf)
+    torch.cuda.synchronize()
+    owned = [(p != 0).float().mean().item() for p in parts]
+    assert all(0.25 < o < 0.42 for o in owned), owned  # balanced thirds
+    assert torch.equal(parts[0] + parts[1] + parts[2], full)
+    with pytest.raises(render.RtxError):
+        cam.render_accumulate(scene, full.data_ptr(), 0, 8, seed=2, stream=st, tile_rank=3, tile_world=3)
+
+
 def test_strict_and_fast_render_agree(render, scenes):
     cfg, bvh = scenes.make("bouncing-spheres", seed=1, width=160, height=90, samples_per_pixel=8)
     scene, cam = render.Scene(bvh), render.Camera(cfg)
