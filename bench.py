@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--traversal", choices=["fast", "strict"], default="fast")
     ap.add_argument("--split", choices=["spp", "tile"], default="spp", help="multi-GPU partition: sample ranges or interleaved 8x8 tiles")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--rr", type=int, default=0, help="Russian roulette start depth (0 = off, as in the reference)")
     ap.add_argument("--cpu-spp", type=int, default=4, help="samples per pixel of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -75,13 +77,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     render = importlib.import_module("ray-tracer_amd.render")
     scenes = importlib.import_module("ray-tracer_amd.scenes")
@@ -159,7 +166,7 @@ def main():
             "config": {"workload": f"{args.scene} seed {args.seed} ({scene.n_prims} primitives), "
                                    f"{cfg.width}x{cfg.height}, {args.spp} spp, depth {args.depth}",
                        "traversal": args.traversal, "russian_roulette_start": args.rr,
-                       "parallelism": f"{args.split}-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
+                       "parallelism": f"{args.split}-split x{world} + {'RCCL' if args.backend == 'nccl' else args.backend} reduce" if world > 1 else "single GPU"},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 1),
             "rays_per_sample": round(total_rays / (samples_per_step * args.steps), 3),
         }

@@ -401,15 +401,16 @@ struct RenderParams {
     uint32_t rr_start;
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
+    uint32_t overlap;     // 1: free lanes start on the wave's next item while the current one drains
     uint32_t* item_counter;
     unsigned long long* ray_counter;
     float* partial;       // [n_batches][H][W][3]
 };
 
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
-constexpr int WAVES_PER_BLOCK = 8;  // all waves of a block share one LDS copy of the entries
+constexpr int WAVES_PER_BLOCK = 12;  // all waves of a block share one LDS copy of the entries
 constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
-constexpr int ACC_FLOATS = 64 * 3;
+constexpr int ACC_FLOATS = 64 * 3;   // one tile accumulator; every wave owns two (items A and B)
 
 extern __shared__ uint4 smem[];
 
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
 
     // LDS: [entries incl. terminator (optional)] [per-wave tile accumulators]
     const uint32_t ent_u4 = ENTS_IN_LDS ? 2u * S.n_ents[M] : 0u;
-    float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * ACC_FLOATS;
+    float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * (2 * ACC_FLOATS);
     if (ENTS_IN_LDS) {
         for (uint32_t i = threadIdx.x; i < ent_u4; i += blockDim.x) smem[i] = gents[i];
         __syncthreads();
@@ -485,32 +486,72 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
         RTX_LOAD_ENTRY(off, ea, eb);     \
     } while (0)
 
-    for (;;) {
-        // ---- claim an item for this wave
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(P.item_counter, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= P.n_items) break;
-        const uint32_t tile = P.tile_rank + (item % P.n_owned) * P.tile_world, batch = item / P.n_owned;
-        const uint32_t tx = (tile % P.tiles_x) * TILE, ty = (tile / P.tiles_x) * TILE;
-        const uint32_t vw = min((uint32_t)TILE, C.width - tx), vh = min((uint32_t)TILE, C.height - ty);
-        const uint32_t s0 = P.sample_begin + batch * P.batch;
-        const uint32_t ns = min(P.batch, P.sample_end - s0);
-        const uint32_t pool_total = 64u * ns;  // pool entry q = (sample q / 64, tile slot q % 64); slots outside the image are skipped
-        uint32_t pool_next = 0;  // wave-uniform
+    // Two items are in flight per wave: A, whose pool is being drained, and B, which free lanes start on as soon as A's
+    // pool is empty.  Without the overlap every item would end with a drain phase in which most lanes sit idle.
+    struct ItemCtx {  // wave-uniform; kept small because it lives in scalar registers
+        uint32_t txy;         // tile origin: x | y << 16
+        uint32_t batch;       // which batch of sample indices
+        uint32_t pool_next;   // pool entry q = (sample q / 64, tile slot q % 64); slots outside the image are skipped
+        uint32_t pool_total;  // 0 = no item
+    };
+    ItemCtx A{}, B{};
+    uint32_t a_sel = 0;  // which half of the wave's accumulator A owns (B owns the other); a lane keeps it in slot bit 6
+    bool more = true;    // the global item counter may still have items
 
-        acc[lane] = 0.0f;
-        acc[lane + 64] = 0.0f;
-        acc[lane + 128] = 0.0f;
-        eb.w = ST_IDLE;
+#define RTX_CLAIM(ctx, sel)                                                                                      \
+    do {                                                                                                         \
+        uint32_t item_ = 0;                                                                                      \
+        if (lane == 0) item_ = atomicAdd(P.item_counter, 1u);                                                    \
+        item_ = __builtin_amdgcn_readfirstlane(item_);                                                           \
+        if (item_ >= P.n_items) {                                                                                \
+            more = false;                                                                                        \
+        } else {                                                                                                 \
+            const uint32_t tile_ = P.tile_rank + (item_ % P.n_owned) * P.tile_world;                             \
+            ctx.batch = item_ / P.n_owned;                                                                       \
+            ctx.txy = ((tile_ % P.tiles_x) * TILE) | (((tile_ / P.tiles_x) * TILE) << 16);                       \
+            ctx.pool_total = 64u * min(P.batch, P.sample_end - (P.sample_begin + ctx.batch * P.batch));          \
+            ctx.pool_next = 0;                                                                                   \
+            acc[(sel) * ACC_FLOATS + lane] = 0.0f;                                                               \
+            acc[(sel) * ACC_FLOATS + lane + 64] = 0.0f;                                                          \
+            acc[(sel) * ACC_FLOATS + lane + 128] = 0.0f;                                                         \
+        }                                                                                                        \
+    } while (0)
 
+    RTX_CLAIM(A, a_sel);
+    eb.w = ST_IDLE;
+    if (A.pool_total != 0u) {
         for (;;) {
             const uint32_t n_box = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
             const uint32_t n_done = (uint32_t)__popcll(__ballot(eb.w == ENT_END));
             const uint32_t n_idle = (uint32_t)__popcll(__ballot(eb.w == ST_IDLE));
             const uint32_t n_prim = 64u - n_box - n_done - n_idle;
-            const uint32_t n_serv = n_done + min(n_idle, pool_total - pool_next);
-            if (n_box + n_prim + n_serv == 0) break;
+            bool a_has = A.pool_next < A.pool_total;
+            if (!a_has) {
+                // retire A once no lane carries one of its paths: write the tile's sums into this batch's partial image
+                // (each pixel of each batch has exactly one writer)
+                if (__ballot(eb.w != ST_IDLE && (slot >> 6) == a_sel) == 0ull) {
+                    const uint32_t a_tx = A.txy & 0xFFFFu, a_ty = A.txy >> 16;
+                    if (a_tx + (lane & 7u) < C.width && a_ty + (lane >> 3) < C.height) {
+                        const uint32_t px = a_tx + (lane & 7u), py = a_ty + (lane >> 3);
+                        float* dst = P.partial + ((size_t)A.batch * C.height * C.width + (size_t)py * C.width + px) * 3;
+                        dst[0] = acc[a_sel * ACC_FLOATS + lane * 3 + 0];
+                        dst[1] = acc[a_sel * ACC_FLOATS + lane * 3 + 1];
+                        dst[2] = acc[a_sel * ACC_FLOATS + lane * 3 + 2];
+                    }
+                    if (B.pool_total == 0u && more) RTX_CLAIM(B, a_sel ^ 1u);
+                    if (B.pool_total == 0u) break;  // nothing left anywhere
+                    A = B;
+                    B.pool_total = 0;
+                    a_sel ^= 1u;
+                    a_has = A.pool_next < A.pool_total;
+                } else if (B.pool_total == 0u && more && P.overlap != 0u) {
+                    RTX_CLAIM(B, a_sel ^ 1u);  // free lanes move on to the next item while A's last paths finish
+                }
+            }
+            const bool b_has = !a_has && B.pool_next < B.pool_total;
+            const uint32_t pool_left = a_has ? A.pool_total - A.pool_next : (b_has ? B.pool_total - B.pool_next : 0u);
+            const uint32_t n_serv = n_done + min(n_idle, pool_left);
+            if (n_box + n_prim + n_serv == 0) continue;  // only possible while A drains a zero-depth pool
 #ifdef RTX_STAGE_COUNTERS
             sc[7]++;
 #endif
@@ -564,7 +605,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
 #ifdef RTX_STAGE_COUNTERS
                 sc[4]++;
                 sc[5] += n_done;
-                sc[6] += min(n_idle, pool_total - pool_next);
+                sc[6] += min(n_idle, pool_left);
 #endif
                 if (eb.w == ENT_END) {
                     eb.w = ST_IDLE;
@@ -627,13 +668,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                 // ---- service stage 2, ray generation: free lanes take the next (pixel, sample) pairs of the pool
                 //      (camera.rs:147-163)
                 const unsigned long long idle = __ballot(eb.w == ST_IDLE);
-                if (idle && pool_next < pool_total) {
-                    const uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (idle && pool_left != 0u) {
+                    // all lanes of one pass draw from one item: A while its pool lasts, then B
+                    const uint32_t g_next = a_has ? A.pool_next : B.pool_next, g_total = a_has ? A.pool_total : B.pool_total;
+                    const uint32_t g_txy = a_has ? A.txy : B.txy, g_batch = a_has ? A.batch : B.batch;
+                    const uint32_t g_tx = g_txy & 0xFFFFu, g_ty = g_txy >> 16;
+                    const uint32_t g_s0 = P.sample_begin + g_batch * P.batch, g_sel = a_has ? a_sel : (a_sel ^ 1u);
+                    const uint32_t my = g_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     const uint32_t my_slot = my & 63u;
-                    const uint32_t x = tx + (my_slot & 7u), y = ty + (my_slot >> 3);
-                    if (eb.w == ST_IDLE && my < pool_total && (my_slot & 7u) < vw && (my_slot >> 3) < vh) {
-                        slot = my_slot;
-                        const uint32_t sample = s0 + (my >> 6);
+                    const uint32_t x = g_tx + (my_slot & 7u), y = g_ty + (my_slot >> 3);
+                    if (eb.w == ST_IDLE && my < g_total && x < C.width && y < C.height) {
+                        slot = my_slot | (g_sel << 6);
+                        const uint32_t sample = g_s0 + (my >> 6);
                         rng = rng_init(P.seed, y * C.width + x, sample);
                         const float ox = rng_f32(rng) - 0.5f;
                         const float oy = rng_f32(rng) - 0.5f;
@@ -660,20 +706,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                         // ray_color(depth 0) is black before any hit test (camera.rs:125): the lane stays free
                         if (depth_left != 0) RTX_BEGIN_WALK();
                     }
-                    pool_next = min(pool_total, pool_next + (uint32_t)__popcll(idle));
+                    const uint32_t g_adv = min(g_total, g_next + (uint32_t)__popcll(idle));
+                    if (a_has) A.pool_next = g_adv; else B.pool_next = g_adv;
                 }
             }
         }
-
-        // ---- write the tile's sums into this batch's partial image (each pixel of each batch has one writer)
-        if ((lane & 7u) < vw && (lane >> 3) < vh) {
-            const uint32_t x = tx + (lane & 7u), y = ty + (lane >> 3);
-            float* dst = P.partial + ((size_t)batch * C.height * C.width + (size_t)y * C.width + x) * 3;
-            dst[0] = acc[lane * 3 + 0];
-            dst[1] = acc[lane * 3 + 1];
-            dst[2] = acc[lane * 3 + 2];
-        }
     }
+#undef RTX_CLAIM
 #undef RTX_LOAD_ENTRY
 #undef RTX_BEGIN_WALK
     // one ray-count update per wave
@@ -755,9 +794,19 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.tiles_y = (cam->height + TILE - 1) / TILE;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t spp = se - sb;
-    // enough items to balance the waves the chip holds (CUs x 32), few enough that an item amortises its setup
-    const uint32_t want_items = (uint32_t)scene->n_cus * 32u * 4u;
-    uint32_t n_batches = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (want_items + n_tiles - 1) / n_tiles));
+    // The sample range is cut into batches so that the chip's waves (CUs x 32) get several items each: many items
+    // balance the tail of the launch, but an item shorter than ~20 samples per pixel spends too much of its life
+    // filling and draining.  Between 4 and 64 items per wave, as many as keep a batch at 20 samples or more.
+    const uint32_t waves = (uint32_t)scene->n_cus * 32u;
+    const uint32_t fixed_ipw = env_u32("RTX_ITEMS_PER_WAVE", 0);
+    uint32_t n_batches;
+    if (fixed_ipw != 0u) {
+        n_batches = (waves * fixed_ipw + n_tiles - 1) / n_tiles;
+    } else {
+        const uint32_t lo = (waves * 4u + n_tiles - 1) / n_tiles, hi = (waves * 64u + n_tiles - 1) / n_tiles;
+        n_batches = std::min(hi, std::max(lo, spp / 20u));
+    }
+    n_batches = std::min<uint32_t>(spp, std::max<uint32_t>(1u, n_batches));
     n_batches = std::min<uint32_t>(n_batches, env_u32("RTX_MAX_BATCHES", 64));
     P.batch = (spp + n_batches - 1) / n_batches;
     P.n_batches = (spp + P.batch - 1) / P.batch;
@@ -771,6 +820,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
     P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 12));
     P.w_serv = std::max<uint32_t>(1u, env_u32("RTX_W_SERV", 5));
+    P.overlap = env_u32("RTX_OVERLAP", 1);
 
     const size_t npix3 = (size_t)cam->width * cam->height * 3;
     const size_t need = npix3 * sizeof(float) * P.n_batches;
@@ -788,7 +838,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     HIP_TRY(hipMemsetAsync(scene->counters, 0, 128, st));
 
     const size_t ent_bytes = (size_t)scene->n_ents[M] * 32;
-    const size_t acc_bytes = WAVES_PER_BLOCK * ACC_FLOATS * sizeof(float);
+    const size_t acc_bytes = WAVES_PER_BLOCK * 2 * ACC_FLOATS * sizeof(float);
     const bool in_lds = ent_bytes <= env_u32("RTX_LDS_ENTS_MAX", 72 * 1024);
     const size_t lds = acc_bytes + (in_lds ? ent_bytes : 0);
     const uint32_t blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / WAVES_PER_BLOCK, (160 * 1024) / (lds + 512))));
