@@ -52,6 +52,7 @@ struct Threaded {
     std::vector<uint32_t> rank;  // per entry: tie-break rank of a primitive / medium entry (first position in the strict order)
     uint32_t n_boxes = 0, n_prims = 0;
     bool has_brackets = false;   // contains transform or medium entries
+    std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
 };
 
 static inline uint32_t fbits(float f) {
@@ -490,10 +491,115 @@ class Builder {
             });
             uint32_t mid = (uint32_t)(midit - units.begin());
             if (mid == begin || mid == end) mid = begin + n / 2;
+            out.inner.push_back(at);
             ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium) && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
         }
         out.ents[at].w[6] = (uint32_t)out.ents.size();
         return ok;
+    }
+};
+
+// A copy of a fast array (entry indices, before finalize) in which the two children of every inner box are visited
+// nearer-to-`view` first.  Rays that start at the viewpoint then meet their closest hit early and cull the far child
+// by distance; the closest hit itself does not depend on the order.  Inside a Translate / RotateY the viewpoint is
+// moved into the object's space.
+class Reorder {
+  public:
+    Reorder(const Threaded& src_, Threaded& dst_) : src(src_), dst(dst_) {}
+
+    void run(const float view[3]) {
+        const uint32_t n = (uint32_t)src.ents.size();
+        is_inner.assign(n, 0);
+        for (uint32_t i : src.inner) is_inner[i] = 1;
+        new_index.assign(n, NONE);
+        old_index.clear();
+        old_index.reserve(n);
+        dst.ents.clear();
+        dst.rank.clear();
+        dst.ents.reserve(n + 1);
+        dst.rank.reserve(n + 1);
+        dst.n_boxes = src.n_boxes;
+        dst.n_prims = src.n_prims;
+        dst.has_brackets = src.has_brackets;
+        dst.inner.clear();
+        for (uint32_t j = 0; j < n;) j = place(j, view);
+        // links that name an entry (not the end of the own subtree) go through the index map
+        for (uint32_t p = 0; p < n; p++) {
+            Ent& e = dst.ents[p];
+            if (e.w[7] == ENT_BOX) continue;
+            const uint32_t kind = e.w[7] & 15u;
+            if (kind == ENT_XF_PUSH || kind == ENT_MED_BEGIN || kind == ENT_MED_END) e.w[6] = new_index[e.w[6]];
+            if ((kind == ENT_XF_PUSH || kind == ENT_XF_POP) && e.w[4] != NONE) e.w[4] = new_index[e.w[4]];
+        }
+    }
+
+  private:
+    const Threaded& src;
+    Threaded& dst;
+    std::vector<uint8_t> is_inner;
+    std::vector<uint32_t> new_index, old_index;
+
+    static float bits_f(uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    }
+    float dist2(uint32_t box, const float view[3]) const {  // squared distance from the viewpoint to a box entry (0 inside)
+        const Ent& e = src.ents[box];
+        float s = 0;
+        for (int a = 0; a < 3; a++) {
+            float g = std::fmax(std::fmax(bits_f(e.w[2 * a]) - view[a], view[a] - bits_f(e.w[2 * a + 1])), 0.0f);
+            s += g * g;
+        }
+        return s;
+    }
+    uint32_t copy(uint32_t i) {
+        const uint32_t p = (uint32_t)dst.ents.size();
+        new_index[i] = p;
+        dst.ents.push_back(src.ents[i]);
+        dst.rank.push_back(src.rank[i]);
+        return p;
+    }
+    // Places entry i with everything under it; returns the old index of the entry that followed it.
+    uint32_t place(uint32_t i, const float view[3]) {
+        const Ent& e = src.ents[i];
+        const uint32_t p = copy(i);
+        if (e.w[7] == ENT_BOX) {
+            const uint32_t end = e.w[6];
+            if (is_inner[i]) {
+                const uint32_t l = i + 1, r = src.ents[l].w[6];
+                dst.inner.push_back(p);
+                if (dist2(r, view) < dist2(l, view)) {
+                    place(r, view);
+                    place(l, view);
+                } else {
+                    place(l, view);
+                    place(r, view);
+                }
+            } else {
+                for (uint32_t j = i + 1; j < end;) j = place(j, view);
+            }
+            dst.ents[p].w[6] = (uint32_t)dst.ents.size();
+            return end;
+        }
+        const uint32_t kind = e.w[7] & 15u;
+        if (kind == ENT_XF_PUSH || kind == ENT_MED_BEGIN) {
+            const uint32_t close = e.w[6];
+            float local[3] = {view[0], view[1], view[2]};
+            if (kind == ENT_XF_PUSH) {
+                if (e.w[0] == 1u) {
+                    for (int a = 0; a < 3; a++) local[a] = view[a] - bits_f(e.w[1 + a]);
+                } else {
+                    const float sn = bits_f(e.w[1]), cs = bits_f(e.w[2]);
+                    local[0] = cs * view[0] - sn * view[2];
+                    local[2] = sn * view[0] + cs * view[2];
+                }
+            }
+            for (uint32_t j = i + 1; j < close;) j = place(j, local);
+            copy(close);
+            return close + 1;
+        }
+        return i + 1;
     }
 };
 
@@ -513,7 +619,7 @@ static inline void finalize(Threaded& t) {
 }
 
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.
-static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, float& coord_range, std::string& err) {
+static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, Threaded& fast_indexed, float& coord_range, std::string& err) {
     Builder b(d);
     if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) b.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTX_SAH_CTRAV")) b.C_TRAV = (float)std::atof(e);
@@ -538,6 +644,7 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     }
     coord_range = b.coord_range;
     if (strict.ents.size() >= (1u << 26) || fast.ents.size() >= (1u << 26)) { err = "scene too large for 32-bit entry offsets"; return RTX_ERR_INVALID; }
+    fast_indexed = fast;  // kept by the scene: re-ordered for a viewpoint when a render asks for it
     finalize(strict);
     finalize(fast);
     return RTX_OK;

@@ -55,6 +55,10 @@ struct rtx_scene {
     int n_cus = 0;
     float coord_range = 0.0f;    // largest |coordinate| the fast boxes were padded for
     bool full_features = false;  // scene uses image or noise textures (uv evaluation, Perlin tables)
+    // the fast array in entry-index form and the viewpoint its device copy is currently ordered for
+    rtx_accel::Threaded fast_indexed;
+    float view[3] = {0, 0, 0};
+    bool view_valid = false;
 };
 
 template <class T>
@@ -157,7 +161,7 @@ extern "C" void rtx_scene_destroy(rtx_scene_t* s) {
 static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     rtx_accel::Threaded strict, fast;
     std::string err;
-    int rc = rtx_accel::build(*d, strict, fast, s->coord_range, err);
+    int rc = rtx_accel::build(*d, strict, fast, s->fast_indexed, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
     if (strict.has_brackets) s->full_features = true;  // transforms / media need the bracket-aware kernel variant
 
@@ -757,6 +761,23 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
     return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
 }
 
+// Re-orders the fast array for rays leaving `center` (children nearer to it are visited first) and replaces the device
+// copy.  Only the visiting order changes: every trace returns the same hit as before.
+static int order_fast_for_view(rtx_scene* scene, const float center[3]) {
+    if (scene->view_valid && std::memcmp(scene->view, center, sizeof(scene->view)) == 0) return RTX_OK;
+    if (!(std::isfinite(center[0]) && std::isfinite(center[1]) && std::isfinite(center[2]))) return RTX_OK;
+    rtx_accel::Threaded ordered;
+    rtx_accel::Reorder(scene->fast_indexed, ordered).run(center);
+    rtx_accel::finalize(ordered);
+    if (ordered.ents.size() != scene->n_ents[RTX_TRAVERSAL_FAST]) return fail(RTX_ERR_DEVICE, "internal: re-ordered array changed size");
+    HIP_TRY(hipDeviceSynchronize());  // no walk may be in flight while the array is replaced
+    HIP_TRY(hipMemcpy(const_cast<uint4*>(scene->dev.ents[RTX_TRAVERSAL_FAST]), ordered.ents.data(), ordered.ents.size() * sizeof(rtx_accel::Ent), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<uint32_t*>(scene->dev.rank[RTX_TRAVERSAL_FAST]), ordered.rank.data(), ordered.rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::memcpy(scene->view, center, sizeof(scene->view));
+    scene->view_valid = true;
+    return RTX_OK;
+}
+
 extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camera_t* cam, const rtx_render_opts_t* opts, float* accum_dev, void* stream,
                                      rtx_stats_t* stats) {
     rtx_scene* scene = const_cast<rtx_scene*>(scene_c);
@@ -782,6 +803,9 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
         float dmax = 0.0f;
         for (int k = 0; k < 3; k++) dmax = std::fmax(dmax, std::fmax(std::fabs(cam->defocus_disk_u[k]), std::fabs(cam->defocus_disk_v[k])));
         if (!(cmax + 2.0f * dmax <= scene->coord_range)) M = RTX_TRAVERSAL_STRICT;
+    }
+    if (M == RTX_TRAVERSAL_FAST && env_u32("RTX_VIEW_ORDER", 1) != 0u) {
+        if ((rc = order_fast_for_view(scene, cam->center)) != RTX_OK) return rc;
     }
     RenderParams P;
     std::memset(&P, 0, sizeof(P));
