@@ -464,12 +464,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     WalkX wx{};
     const EntReader reader{ENTS_IN_LDS ? reinterpret_cast<const uint4*>(smem) : gents};
 
+    // The entries start at LDS address 0 (this kernel has no static LDS, checked below), so a byte offset is already
+    // the LDS address of an entry and no base needs adding per load.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const u32x4 lds_u4;
+    if (ENTS_IN_LDS && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
 #define RTX_LOAD_ENTRY(o, a, b)                                                \
     do {                                                                       \
         if (ENTS_IN_LDS) {                                                     \
-            const char* base_ = reinterpret_cast<const char*>(smem) + (o);     \
-            a = *reinterpret_cast<const uint4*>(base_);                        \
-            b = *reinterpret_cast<const uint4*>(base_ + 16);                   \
+            lds_u4* base_ = (lds_u4*)(uintptr_t)(uint32_t)(o);                 \
+            const u32x4 a_ = base_[0], b_ = base_[1];                          \
+            a = make_uint4(a_.x, a_.y, a_.z, a_.w);                            \
+            b = make_uint4(b_.x, b_.y, b_.z, b_.w);                            \
         } else {                                                               \
             const char* base_ = reinterpret_cast<const char*>(gents) + (o);    \
             a = *reinterpret_cast<const uint4*>(base_);                        \

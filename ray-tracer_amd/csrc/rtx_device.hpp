@@ -169,6 +169,12 @@ __device__ __forceinline__ bool slab_hit(const uint4& ea, const uint4& eb, const
         hi = z0 < z1 ? z1 : z0;
         tmin = fmaxf(tmin, lo);
         tmax = fminf(tmax, hi);
+    } else if (SLAB == SLAB_FMA) {
+        tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+        // The interval end comes from memory, so fminf would first re-quiet it on every call; the instruction itself
+        // needs no such step (a NaN operand drops out, as in fminf).
+        const float exit3 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        asm("v_min_f32 %0, %1, %2" : "=v"(tmax) : "v"(exit3), "v"(tmax));
     } else {
         tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
         tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
