@@ -255,7 +255,10 @@ int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_r
 /* Camera::render_pixel's sample loop (camera.rs:109-122) for the samples [sample_begin, sample_end) of every
  * pixel: ADDS their radiance sum into accum_dev (3*W*H f32, device memory, caller zeroes it).  This is the
  * unit that multi-GPU sample splitting shards; the buffers of all ranks are summed before rtx_resolve.
- * Asynchronous on `stream` unless stats is non-null (then it synchronises the stream to read the timers). */
+ * Asynchronous on `stream` unless stats is non-null (then it synchronises the stream to read the timers).
+ * With RTX_TRAVERSAL_FAST the first call, and any call whose camera centre differs from the previous one's, first
+ * waits for the device and re-orders the scene's fast traversal data for that viewpoint (nearer subtrees are
+ * visited first; hits are unchanged).  Calls on one scene must therefore not overlap. */
 int rtx_render_accumulate(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
                           float* accum_dev, void* stream, rtx_stats_t* stats);
 
