@@ -54,7 +54,8 @@ struct rtx_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 0;
     float coord_range = 0.0f;    // largest |coordinate| the fast boxes were padded for
-    bool full_features = false;  // scene uses image or noise textures (uv evaluation, Perlin tables)
+    bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
+    bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
     // the fast array in entry-index form and the viewpoint its device copy is currently ordered for
     rtx_accel::Threaded fast_indexed;
     float view[3] = {0, 0, 0};
@@ -163,7 +164,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     std::string err;
     int rc = rtx_accel::build(*d, strict, fast, s->fast_indexed, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
-    if (strict.has_brackets) s->full_features = true;  // transforms / media need the bracket-aware kernel variant
+    if (strict.has_brackets) s->has_brackets = true;  // transforms / media need the bracket-aware kernel variant
 
     HIP_TRY(hipGetDevice(&s->device));
     hipDeviceProp_t prop;
@@ -244,7 +245,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     }
     if ((rc = upload(s, texs, &s->dev.texs)) != RTX_OK) return rc;
     for (uint32_t i = 0; i < d->n_textures; i++)
-        if (d->textures[i].kind == RTX_TEX_IMAGE || d->textures[i].kind == RTX_TEX_NOISE) s->full_features = true;
+        if (d->textures[i].kind == RTX_TEX_IMAGE || d->textures[i].kind == RTX_TEX_NOISE) s->has_tex = true;
 
     std::vector<DevImage> images(d->n_images);
     for (uint32_t i = 0; i < d->n_images; i++) {
@@ -412,8 +413,8 @@ struct RenderParams {
 };
 
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
-constexpr int WAVES_PER_BLOCK = 12;  // all waves of a block share one LDS copy of the entries
-constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+constexpr int MAX_WAVES_PER_BLOCK = 12;  // all waves of a block share one LDS copy of the entries; the launch picks 4, 8 or 12
+constexpr int BLOCK_THREADS = 64 * MAX_WAVES_PER_BLOCK;
 constexpr int ACC_FLOATS = 64 * 3;   // one tile accumulator; every wave owns two (items A and B)
 
 extern __shared__ uint4 smem[];
@@ -426,7 +427,7 @@ extern __shared__ uint4 smem[];
 // fullest -- box tests, primitive tests, or service (shade + scatter, then ray generation for the lanes that became
 // free) -- for exactly the lanes queued for it.  Lanes are never moved: compaction happens in time, by always running
 // the stage most lanes wait for.
-template <bool STRICT, bool ENTS_IN_LDS, bool FULL>
+template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX>
 __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
     float br = 0, bg = 0, bb = 0;  // path throughput
     uint32_t slot = 0, depth_left = 0;
     Rng rng{};
-    // FULL only: the caller's (world) ray and the bracket state of the walk (transforms, media)
+    // XF only: the caller's (world) ray and the bracket state of the walk (transforms, media)
     Ray wray{};
     WalkX wx{};
     const EntReader reader{ENTS_IN_LDS ? reinterpret_cast<const uint4*>(smem) : gents};
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
         rc = ray_const<SLAB>(ray);       \
         best.t = __builtin_inff();       \
         best.ent = NO_HIT;               \
-        if (FULL) {                      \
+        if (XF) {                        \
             wray = ray;                  \
             walkx_init(wx, tmin);         \
         }                                \
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                     sc[1] += __popcll(__ballot(eb.w == ENT_BOX));
 #endif
                     if (eb.w == ENT_BOX) {
-                        const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, FULL ? wx.tmin : tmin, best.t);
+                        const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, XF ? wx.tmin : tmin, best.t);
                         off = hit ? off + ENT_BYTES : eb.z;
                         RTX_LOAD_ENTRY(off, ea, eb);
                     }
@@ -593,8 +594,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
 #endif
                 if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
                     const uint32_t kind = eb.w & 15u;
-                    const float lane_tmin = FULL ? wx.tmin : tmin;
-                    if (FULL && kind >= ENT_XF_PUSH) {
+                    const float lane_tmin = XF ? wx.tmin : tmin;
+                    if (XF && kind >= ENT_XF_PUSH) {
                         // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
                         bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
                     } else {
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                             const bool tri = kind == ENT_TRI;
                             planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
                         }
-                        if (FULL && best.ent == off) wx.best_xf = wx.cur_xf;
+                        if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
                         off += ENT_BYTES;
                     }
                     RTX_LOAD_ENTRY(off, ea, eb);
@@ -625,24 +626,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                         atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
                     } else {
                         HitRec h;
-                        if (FULL) {
+                        {
                             uint4 ha, hb;
                             RTX_LOAD_ENTRY(best.ent, ha, hb);
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
-                            const uint32_t kind = hb.w & 15u;
                             bool want_uv = false;
-                            if (kind <= ENT_TRI) {
-                                const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
-                                                                        : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
-                                want_uv = (S.mats[mat].w & 1u) != 0u;
+                            if (TEX) {
+                                const uint32_t kind = hb.w & 15u;
+                                if (kind <= ENT_TRI) {
+                                    const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
+                                                                            : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
+                                    want_uv = (S.mats[mat].w & 1u) != 0u;
+                                }
                             }
-                            h = want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
-                        } else {
-                            uint4 ha, hb;
-                            RTX_LOAD_ENTRY(best.ent, ha, hb);
-                            h = make_hit<false, false>(S, ha, hb, ray, best.t);
+                            if (XF) {
+                                h = TEX && want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
+                            } else {
+                                h = TEX && want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
+                            }
                         }
-                        ScatterOut so = shade<FULL>(S, ray, h, rng);
+                        ScatterOut so = shade<TEX>(S, ray, h, rng);
                         if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
                             atomicAdd(&acc[slot * 3 + 0], br * so.er);
                             atomicAdd(&acc[slot * 3 + 1], bg * so.eg);
@@ -868,21 +871,46 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     HIP_TRY(hipMemsetAsync(scene->counters, 0, 128, st));
 
     const size_t ent_bytes = (size_t)scene->n_ents[M] * 32;
-    const size_t acc_bytes = WAVES_PER_BLOCK * 2 * ACC_FLOATS * sizeof(float);
     const bool in_lds = ent_bytes <= env_u32("RTX_LDS_ENTS_MAX", 72 * 1024);
-    const size_t lds = acc_bytes + (in_lds ? ent_bytes : 0);
-    const uint32_t blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / WAVES_PER_BLOCK, (160 * 1024) / (lds + 512))));
-    dim3 block(64 * WAVES_PER_BLOCK), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+    // one instantiation per (traversal, entries in LDS, brackets, uv / noise textures): features a scene does not use
+    // cost registers, and registers cost resident waves
+    static void (*const kernels[16])(RenderParams) = {
+        render_kernel<false, false, false, false>, render_kernel<false, false, false, true>, render_kernel<false, false, true, false>,
+        render_kernel<false, false, true, true>,   render_kernel<false, true, false, false>, render_kernel<false, true, false, true>,
+        render_kernel<false, true, true, false>,   render_kernel<false, true, true, true>,   render_kernel<true, false, false, false>,
+        render_kernel<true, false, false, true>,   render_kernel<true, false, true, false>,  render_kernel<true, false, true, true>,
+        render_kernel<true, true, false, false>,   render_kernel<true, true, false, true>,   render_kernel<true, true, true, false>,
+        render_kernel<true, true, true, true>};
+    void (*kern)(RenderParams) = kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
-    void (*kern)(RenderParams) = nullptr;
-    const bool full = scene->full_features;
-    if (M == RTX_TRAVERSAL_STRICT) {
-        if (full) kern = in_lds ? render_kernel<true, true, true> : render_kernel<true, false, true>;
-        else kern = in_lds ? render_kernel<true, true, false> : render_kernel<true, false, false>;
-    } else {
-        if (full) kern = in_lds ? render_kernel<false, true, true> : render_kernel<false, false, true>;
-        else kern = in_lds ? render_kernel<false, true, false> : render_kernel<false, false, false>;
+    // Block shape: a block is 4, 8 or 12 waves (1, 2 or 3 per SIMD).  The variant's register count says how many waves a
+    // SIMD can hold (512 VGPRs each, allocated in eights); take the shape that makes the most waves resident within
+    // the 160 KB of LDS, and on a tie the larger block (fewer LDS copies of the entries).
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, (const void*)kern));
+    const uint32_t vgprs = (uint32_t)std::max(fa.numRegs, 8);
+    const uint32_t waves_per_simd = std::max(1u, std::min(8u, 512u / ((vgprs + 7u) & ~7u)));
+    uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
+    size_t lds = 0;
+    for (uint32_t b = 1; b <= 3; b++) {
+        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * ACC_FLOATS * sizeof(float);
+        const uint32_t fit = (uint32_t)std::min<size_t>(waves_per_simd / b, (160 * 1024) / (l + 2048));
+        if (fit * b >= best_resident && fit > 0) {
+            best_resident = fit * b;
+            wpb = 4 * b;
+            blocks_per_cu = fit;
+            lds = l;
+        }
     }
+    if (best_resident == 0) return fail(RTX_ERR_DEVICE, "internal: no block shape fits");
+    wpb = std::min<uint32_t>(MAX_WAVES_PER_BLOCK, std::max<uint32_t>(4u, env_u32("RTX_WAVES_PER_BLOCK", wpb) & ~3u));
+    blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", blocks_per_cu);
+    lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * 2 * ACC_FLOATS * sizeof(float);
+    dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
+    if (env_u32("RTX_DEBUG", 0))
+        std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u batches of %u spp, %u items\n", vgprs, wpb,
+                     blocks_per_cu, lds, P.n_batches, P.batch, P.n_items);
+
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     HIP_TRY(hipEventRecord(scene->ev0, st));
