@@ -406,6 +406,7 @@ struct RenderParams {
     uint32_t rr_start;
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
+    uint32_t sched_kp;    // primitive stage keeps running while n_prim * sched_kp >= 8 * lanes queued elsewhere (0 = one step)
     uint32_t overlap;     // 1: free lanes start on the wave's next item while the current one drains
     uint32_t* item_counter;
     unsigned long long* ray_counter;
@@ -428,7 +429,7 @@ extern __shared__ uint4 smem[];
 // free) -- for exactly the lanes queued for it.  Lanes are never moved: compaction happens in time, by always running
 // the stage most lanes wait for.
 template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_kernel(RenderParams P) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
     const DevScene& S = P.S;
@@ -587,30 +588,36 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(RenderParams P) {
                     nb = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
                 } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
             } else if (n_prim != 0u && (sc_prim >= sc_serv || n_serv == 0u)) {
-                // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive
+                // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive; repeated
+                //      while primitives stay the bulk of the work (lists, leaves and instances put them in a row)
+                const uint32_t n_fixed = n_box + n_prim + n_serv;
+                uint32_t np;
+                do {
 #ifdef RTX_STAGE_COUNTERS
-                sc[2]++;
-                sc[3] += n_prim;
+                    sc[2]++;
+                    sc[3] += __popcll(__ballot(eb.w - 1u < ENT_END - 1u));
 #endif
-                if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
-                    const uint32_t kind = eb.w & 15u;
-                    const float lane_tmin = XF ? wx.tmin : tmin;
-                    if (XF && kind >= ENT_XF_PUSH) {
-                        // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
-                        bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
-                    } else {
-                        if (kind == ENT_SPHERE) {
-                            sphere_test<STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);
+                    if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
+                        const uint32_t kind = eb.w & 15u;
+                        const float lane_tmin = XF ? wx.tmin : tmin;
+                        if (XF && kind >= ENT_XF_PUSH) {
+                            // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
+                            bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
                         } else {
-                            const uint32_t pi = eb.w >> 4;
-                            const bool tri = kind == ENT_TRI;
-                            planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                            if (kind == ENT_SPHERE) {
+                                sphere_test<STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);
+                            } else {
+                                const uint32_t pi = eb.w >> 4;
+                                const bool tri = kind == ENT_TRI;
+                                planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                            }
+                            if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
+                            off += ENT_BYTES;
                         }
-                        if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
-                        off += ENT_BYTES;
+                        RTX_LOAD_ENTRY(off, ea, eb);
                     }
-                    RTX_LOAD_ENTRY(off, ea, eb);
-                }
+                    np = (uint32_t)__popcll(__ballot(eb.w - 1u < ENT_END - 1u));
+                } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // without instances primitives rarely queue in a row and the loop would cost the lean variant registers
             } else {
                 // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
 #ifdef RTX_STAGE_COUNTERS
@@ -853,6 +860,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
     P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 12));
     P.w_serv = std::max<uint32_t>(1u, env_u32("RTX_W_SERV", 5));
+    P.sched_kp = env_u32("RTX_SCHED_KP", 32);
     P.overlap = env_u32("RTX_OVERLAP", 1);
 
     const size_t npix3 = (size_t)cam->width * cam->height * 3;
