@@ -507,7 +507,9 @@ class Reorder {
   public:
     Reorder(const Threaded& src_, Threaded& dst_) : src(src_), dst(dst_) {}
 
-    void run(const float view[3]) {
+    // grow: every box is enlarged by this much on all sides (a viewpoint outside the range the boxes were padded for)
+    void run(const float view[3], float grow = 0.0f) {
+        grow_ = grow;
         const uint32_t n = (uint32_t)src.ents.size();
         is_inner.assign(n, 0);
         for (uint32_t i : src.inner) is_inner[i] = 1;
@@ -538,6 +540,7 @@ class Reorder {
     Threaded& dst;
     std::vector<uint8_t> is_inner;
     std::vector<uint32_t> new_index, old_index;
+    float grow_ = 0.0f;
 
     static float bits_f(uint32_t u) {
         float f;
@@ -558,6 +561,13 @@ class Reorder {
         new_index[i] = p;
         dst.ents.push_back(src.ents[i]);
         dst.rank.push_back(src.rank[i]);
+        if (grow_ > 0.0f && src.ents[i].w[7] == ENT_BOX) {
+            Ent& e = dst.ents.back();
+            for (int a = 0; a < 3; a++) {
+                e.w[2 * a] = fbits(bits_f(e.w[2 * a]) - grow_);
+                e.w[2 * a + 1] = fbits(bits_f(e.w[2 * a + 1]) + grow_);
+            }
+        }
         return p;
     }
     // Places entry i with everything under it; returns the old index of the entry that followed it.

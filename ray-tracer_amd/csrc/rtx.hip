@@ -59,6 +59,7 @@ struct rtx_scene {
     // the fast array in entry-index form and the viewpoint its device copy is currently ordered for
     rtx_accel::Threaded fast_indexed;
     float view[3] = {0, 0, 0};
+    float view_grow = 0.0f;
     bool view_valid = false;
 };
 
@@ -778,18 +779,21 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 }
 
 // Re-orders the fast array for rays leaving `center` (children nearer to it are visited first) and replaces the device
-// copy.  Only the visiting order changes: every trace returns the same hit as before.
-static int order_fast_for_view(rtx_scene* scene, const float center[3]) {
-    if (scene->view_valid && std::memcmp(scene->view, center, sizeof(scene->view)) == 0) return RTX_OK;
-    if (!(std::isfinite(center[0]) && std::isfinite(center[1]) && std::isfinite(center[2]))) return RTX_OK;
+// copy.  Only the visiting order changes: every trace returns the same hit as before.  `reach` is the largest
+// |coordinate| a camera ray can start from; beyond the range the boxes were padded for, they are enlarged by the
+// rounding error of the fused box test at that distance (~1.2e-7 * |origin| per plane, taken 4x).
+static int order_fast_for_view(rtx_scene* scene, const float center[3], float reach) {
+    const float grow = reach > scene->coord_range ? 4.5e-7f * reach : 0.0f;
+    if (scene->view_valid && std::memcmp(scene->view, center, sizeof(scene->view)) == 0 && grow == scene->view_grow) return RTX_OK;
     rtx_accel::Threaded ordered;
-    rtx_accel::Reorder(scene->fast_indexed, ordered).run(center);
+    rtx_accel::Reorder(scene->fast_indexed, ordered).run(center, grow);
     rtx_accel::finalize(ordered);
     if (ordered.ents.size() != scene->n_ents[RTX_TRAVERSAL_FAST]) return fail(RTX_ERR_DEVICE, "internal: re-ordered array changed size");
     HIP_TRY(hipDeviceSynchronize());  // no walk may be in flight while the array is replaced
     HIP_TRY(hipMemcpy(const_cast<uint4*>(scene->dev.ents[RTX_TRAVERSAL_FAST]), ordered.ents.data(), ordered.ents.size() * sizeof(rtx_accel::Ent), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<uint32_t*>(scene->dev.rank[RTX_TRAVERSAL_FAST]), ordered.rank.data(), ordered.rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     std::memcpy(scene->view, center, sizeof(scene->view));
+    scene->view_grow = grow;
     scene->view_valid = true;
     return RTX_OK;
 }
@@ -814,14 +818,17 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
 
     uint32_t M = opts->traversal;
     if (M == RTX_TRAVERSAL_FAST) {
-        // the fused box test of the fast walk is padded for ray origins inside the scene's coordinate range
+        // The fused box test of the fast walk needs boxes padded for the distance rays start from: the scene's own
+        // coordinate range covers bounce rays, the camera's position is covered when the array is ordered for it.
         float cmax = std::fmax(std::fabs(cam->center[0]), std::fmax(std::fabs(cam->center[1]), std::fabs(cam->center[2])));
         float dmax = 0.0f;
         for (int k = 0; k < 3; k++) dmax = std::fmax(dmax, std::fmax(std::fabs(cam->defocus_disk_u[k]), std::fabs(cam->defocus_disk_v[k])));
-        if (!(cmax + 2.0f * dmax <= scene->coord_range)) M = RTX_TRAVERSAL_STRICT;
-    }
-    if (M == RTX_TRAVERSAL_FAST && env_u32("RTX_VIEW_ORDER", 1) != 0u) {
-        if ((rc = order_fast_for_view(scene, cam->center)) != RTX_OK) return rc;
+        const float reach = cmax + 2.0f * dmax;
+        if (!std::isfinite(reach) || reach > 1e12f) {
+            M = RTX_TRAVERSAL_STRICT;
+        } else if (env_u32("RTX_VIEW_ORDER", 1) != 0u || reach > scene->coord_range) {
+            if ((rc = order_fast_for_view(scene, cam->center, reach)) != RTX_OK) return rc;
+        }
     }
     RenderParams P;
     std::memset(&P, 0, sizeof(P));
