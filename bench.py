@@ -191,6 +191,7 @@ def main():
                        "parallelism": f"{args.split}-split x{world} + {'RCCL' if args.backend == 'nccl' else args.backend} reduce" if world > 1 else "single GPU"},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 1),
             "rays_per_sample": round(total_rays / (samples_per_step * args.steps), 3),
+            "kernel_ms": round(float(np.mean(kernel_ms)), 3),  # rank 0's render_kernel, HIP events on the launch stream
         }
         if args.save:
             from PIL import Image
