@@ -266,6 +266,14 @@ int rtx_render_accumulate(const rtx_scene_t* scene, const rtx_camera_t* camera, 
 int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float scale, uint8_t* rgb8_dev,
                 void* stream);
 
+/* Inspection, host only (no device is touched; no counterpart in the reference): writes the traversal data that
+ * rtx_scene_create builds for `desc` -- 8 words per 32-byte entry as the kernels read them, links as byte offsets,
+ * terminator last -- and the tie-break rank per entry.  traversal = RTX_TRAVERSAL_*.  view (nullable, 3 floats): order
+ * the fast data for that viewpoint as a render from there would; grow: enlarge every fast box by this much.
+ * With entries_out == NULL only *n_entries is set.  Used by the CPU test-suite to walk the data without a GPU. */
+int rtx_traversal_dump(const rtx_scene_desc_t* desc, uint32_t traversal, const float* view, float grow,
+                       uint32_t* entries_out, uint32_t* rank_out, size_t capacity, size_t* n_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -508,8 +508,9 @@ class Reorder {
     Reorder(const Threaded& src_, Threaded& dst_) : src(src_), dst(dst_) {}
 
     // grow: every box is enlarged by this much on all sides (a viewpoint outside the range the boxes were padded for)
-    void run(const float view[3], float grow = 0.0f) {
+    void run(const float view[3], float grow = 0.0f, bool reorder = true) {
         grow_ = grow;
+        reorder_ = reorder;  // false: keep the build order, only enlarge the boxes
         const uint32_t n = (uint32_t)src.ents.size();
         is_inner.assign(n, 0);
         for (uint32_t i : src.inner) is_inner[i] = 1;
@@ -541,6 +542,7 @@ class Reorder {
     std::vector<uint8_t> is_inner;
     std::vector<uint32_t> new_index, old_index;
     float grow_ = 0.0f;
+    bool reorder_ = true;
 
     static float bits_f(uint32_t u) {
         float f;
@@ -579,7 +581,7 @@ class Reorder {
             if (is_inner[i]) {
                 const uint32_t l = i + 1, r = src.ents[l].w[6];
                 dst.inner.push_back(p);
-                if (dist2(r, view) < dist2(l, view)) {
+                if (reorder_ && dist2(r, view) < dist2(l, view)) {
                     place(r, view);
                     place(l, view);
                 } else {

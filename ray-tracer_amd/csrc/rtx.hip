@@ -160,6 +160,33 @@ extern "C" void rtx_scene_destroy(rtx_scene_t* s) {
     delete s;
 }
 
+extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal, const float* view, float grow, uint32_t* entries_out,
+                                  uint32_t* rank_out, size_t capacity, size_t* n_entries) {
+    if (!n_entries) return fail(RTX_ERR_INVALID, "null argument");
+    if (traversal > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    int rc = validate(d);
+    if (rc != RTX_OK) return rc;
+    rtx_accel::Threaded strict, fast, indexed;
+    std::string err;
+    float range = 0.0f;
+    rc = rtx_accel::build(*d, strict, fast, indexed, range, err);
+    if (rc != RTX_OK) return fail(rc, err);
+    if (traversal == RTX_TRAVERSAL_FAST && (view || grow > 0.0f)) {
+        const float origin[3] = {0.0f, 0.0f, 0.0f};
+        rtx_accel::Threaded ordered;
+        rtx_accel::Reorder(indexed, ordered).run(view ? view : origin, grow, view != nullptr);
+        rtx_accel::finalize(ordered);
+        fast = ordered;
+    }
+    const rtx_accel::Threaded& t = traversal == RTX_TRAVERSAL_STRICT ? strict : fast;
+    *n_entries = t.ents.size();
+    if (!entries_out) return RTX_OK;
+    if (capacity < t.ents.size()) return fail(RTX_ERR_INVALID, "capacity too small");
+    std::memcpy(entries_out, t.ents.data(), t.ents.size() * sizeof(rtx_accel::Ent));
+    if (rank_out) std::memcpy(rank_out, t.rank.data(), t.rank.size() * sizeof(uint32_t));
+    return RTX_OK;
+}
+
 static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     rtx_accel::Threaded strict, fast;
     std::string err;

@@ -110,7 +110,7 @@ _host = None
 _rtx = None
 
 RTX_SYMBOLS = ["rtx_device_count", "rtx_last_error", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace", "rtx_trace_device",
-               "rtx_render", "rtx_render_accumulate", "rtx_resolve"]
+               "rtx_render", "rtx_render_accumulate", "rtx_resolve", "rtx_traversal_dump"]
 
 
 def rtx():
@@ -132,6 +132,8 @@ def rtx():
     L.rtx_render.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
     L.rtx_render_accumulate.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
     L.rtx_resolve.argtypes = [V, C.c_uint32, C.c_uint32, C.c_float, V, V]
+    L.rtx_traversal_dump.argtypes = [C.POINTER(SceneDesc), C.c_uint32, capi.c_float_p, C.c_float, capi.c_u32_p, capi.c_u32_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]
     _rtx = L
     return L
 
@@ -200,6 +202,20 @@ class Scene:
         if not d:
             raise RuntimeError("scene is not uploaded")
         return d
+
+    def traversal_dump(self, traversal=TRAVERSAL_FAST, view=None, grow=0.0):
+        """(entries [n, 8] uint32, rank [n] uint32): the threaded array the kernels would walk (host only, no GPU)."""
+        n = C.c_size_t(0)
+        vp = None
+        if view is not None:
+            varr = np.ascontiguousarray(view, dtype=F)
+            vp = varr.ctypes.data_as(capi.c_float_p)
+        _check(rtx().rtx_traversal_dump(C.byref(self.desc), traversal, vp, grow, None, None, 0, C.byref(n)))
+        ents = np.zeros((n.value, 8), dtype=np.uint32)
+        rank = np.zeros(n.value, dtype=np.uint32)
+        _check(rtx().rtx_traversal_dump(C.byref(self.desc), traversal, vp, grow, ents.ctypes.data_as(capi.c_u32_p),
+                                        rank.ctypes.data_as(capi.c_u32_p), n.value, C.byref(n)))
+        return ents, rank
 
     def bbox(self):
         out = (C.c_float * 6)()
