@@ -229,6 +229,9 @@ extern "C" {
     pub fn rtx_render_accumulate(scene: *const rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, accum_dev: *mut f32,
                                  stream: *mut c_void, stats: *mut rtx_stats_t) -> c_int;
     pub fn rtx_resolve(accum_dev: *const f32, width: u32, height: u32, scale: f32, rgb8_dev: *mut u8, stream: *mut c_void) -> c_int;
+    /// Host-only inspection of the traversal data (no device is touched).
+    pub fn rtx_traversal_dump(desc: *const rtx_scene_desc_t, traversal: u32, view: *const f32, grow: f32, entries_out: *mut u32, rank_out: *mut u32,
+                              capacity: usize, n_entries: *mut usize) -> c_int;
 }
 
 /// Text of the last failure on this thread.
