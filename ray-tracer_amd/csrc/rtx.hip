@@ -478,6 +478,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
     unsigned long long rays_traced = 0;
 #ifdef RTX_STAGE_COUNTERS
     unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
+    unsigned long long tc[4] = {0, 0, 0, 0};              // wave clocks inside the box / primitive / service stage, and in total
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#define RTX_TIC() const unsigned long long tic_ = __builtin_readcyclecounter()
+#define RTX_TOC(i) tc[i] += __builtin_readcyclecounter() - tic_
+#else
+#define RTX_TIC()
+#define RTX_TOC(i)
 #endif
 
     // per-lane path state
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                 //      largest queue (one ballot per step: everything that is not BOX is "the rest")
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
                 uint32_t nb;
+                RTX_TIC();
                 do {
 #ifdef RTX_STAGE_COUNTERS
                     sc[0]++;
@@ -615,11 +623,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                     }
                     nb = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
                 } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
+                RTX_TOC(0);
             } else if (n_prim != 0u && (sc_prim >= sc_serv || n_serv == 0u)) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive; repeated
                 //      while primitives stay the bulk of the work (lists, leaves and instances put them in a row)
                 const uint32_t n_fixed = n_box + n_prim + n_serv;
                 uint32_t np;
+                RTX_TIC();
                 do {
 #ifdef RTX_STAGE_COUNTERS
                     sc[2]++;
@@ -646,8 +656,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                     }
                     np = (uint32_t)__popcll(__ballot(eb.w - 1u < ENT_END - 1u));
                 } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // without instances primitives rarely queue in a row and the loop would cost the lean variant registers
+                RTX_TOC(1);
             } else {
                 // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
+                RTX_TIC();
 #ifdef RTX_STAGE_COUNTERS
                 sc[4]++;
                 sc[5] += n_done;
@@ -757,6 +769,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                     const uint32_t g_adv = min(g_total, g_next + (uint32_t)__popcll(idle));
                     if (a_has) A.pool_next = g_adv; else B.pool_next = g_adv;
                 }
+                RTX_TOC(2);
             }
         }
     }
@@ -767,9 +780,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
     for (int o = 32; o > 0; o >>= 1) rays_traced += __shfl_down(rays_traced, o);
     if (lane == 0 && rays_traced) atomicAdd(P.ray_counter, rays_traced);
 #ifdef RTX_STAGE_COUNTERS
-    if (lane == 0)
+    tc[3] = __builtin_readcyclecounter() - t_begin;
+    if (lane == 0) {
         for (int i = 0; i < 8; i++) atomicAdd(P.ray_counter + 1 + i, sc[i]);
+        for (int i = 0; i < 4; i++) atomicAdd(P.ray_counter + 9 + i, tc[i]);
+    }
 #endif
+#undef RTX_TIC
+#undef RTX_TOC
 }
 
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ partial, uint32_t n_batches, size_t n, float* __restrict__ accum, uint32_t width,
@@ -977,8 +995,10 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
         stats->n_launches = 1;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 #ifdef RTX_STAGE_COUNTERS
-        unsigned long long sc[8];
-        HIP_TRY(hipMemcpy(sc, scene->counters + 4, 64, hipMemcpyDeviceToHost));
+        unsigned long long sc[12];
+        HIP_TRY(hipMemcpy(sc, scene->counters + 4, 96, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[stage clocks] box %.1f%% primitive %.1f%% service %.1f%% scheduling and item turnover %.1f%% of the waves' time\n", 100.0 * sc[8] / sc[11],
+                     100.0 * sc[9] / sc[11], 100.0 * sc[10] / sc[11], 100.0 * (sc[11] - sc[8] - sc[9] - sc[10]) / sc[11]);
         double r = (double)nrays;
         std::fprintf(stderr, "[stages] rays %.3g | box steps %.3g lanes/step %.1f tests/ray %.2f | prim steps %.3g lanes/step %.1f tests/ray %.2f | service %.3g shade lanes/pass %.1f gen lanes/pass %.1f | sched passes %.3g\n", r,
                      (double)sc[0], (double)sc[1] / sc[0], sc[1] / r, (double)sc[2], (double)sc[3] / sc[2], sc[3] / r, (double)sc[4], (double)sc[5] / sc[4], (double)sc[6] / sc[4], (double)sc[7]);
