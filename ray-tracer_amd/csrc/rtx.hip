@@ -442,7 +442,7 @@ struct RenderParams {
 };
 
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
-constexpr int MAX_WAVES_PER_BLOCK = 12;  // all waves of a block share one LDS copy of the entries; the launch picks 4, 8 or 12
+constexpr int MAX_WAVES_PER_BLOCK = 16;  // all waves of a block share one LDS copy of the entries; the launch picks 4, 8, 12 or 16
 constexpr int BLOCK_THREADS = 64 * MAX_WAVES_PER_BLOCK;
 constexpr int ACC_FLOATS = 64 * 3;   // one tile accumulator; every wave owns two (items A and B)
 
@@ -457,7 +457,7 @@ extern __shared__ uint4 smem[];
 // free) -- for exactly the lanes queued for it.  Lanes are never moved: compaction happens in time, by always running
 // the stage most lanes wait for.
 template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX>
-__global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_kernel(RenderParams P) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
     const DevScene& S = P.S;
@@ -488,8 +488,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
 #endif
 
     // per-lane path state
-    uint32_t off = 0;                            // byte offset of the entry the lane stands at
-    uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;  // that entry; eb.w is the lane's queue
+    uint32_t off = 0;       // byte offset of the entry the lane stands at
+    uint32_t st = ST_IDLE;  // word 7 of that entry = the lane's queue.  Only these two cross from stage to stage: an
+                            // entry itself is loaded by the stage that consumes it, so its eight registers are free
+                            // everywhere else and no copies are needed where the stages' control flow merges
     Ray ray{};
     RayConst rc{};
     Best best{};
@@ -519,6 +521,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
             b = *reinterpret_cast<const uint4*>(base_ + 16);                   \
         }                                                                      \
     } while (0)
+#define RTX_LOAD_STATE(o, w)                                                                          \
+    do {                                                                                             \
+        if (ENTS_IN_LDS) {                                                                           \
+            w = *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(uint32_t)((o) + 28u); \
+        } else {                                                                                     \
+            w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(gents) + (o) + 28u); \
+        }                                                                                            \
+    } while (0)
+    uint32_t root_st;  // queue of the first entry (wave-uniform)
+    RTX_LOAD_STATE(0u, root_st);
+    root_st = __builtin_amdgcn_readfirstlane(root_st);
 #define RTX_BEGIN_WALK()                 \
     do {                                 \
         rc = ray_const<SLAB>(ray);       \
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
         }                                \
         rays_traced++;                   \
         off = 0;                         \
-        RTX_LOAD_ENTRY(off, ea, eb);     \
+        st = root_st;                    \
     } while (0)
 
     // Two items are in flight per wave: A, whose pool is being drained, and B, which free lanes start on as soon as A's
@@ -565,18 +578,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
     } while (0)
 
     RTX_CLAIM(A, a_sel);
-    eb.w = ST_IDLE;
     if (A.pool_total != 0u) {
         for (;;) {
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
-            const uint32_t n_done = (uint32_t)__popcll(__ballot(eb.w == ENT_END));
-            const uint32_t n_idle = (uint32_t)__popcll(__ballot(eb.w == ST_IDLE));
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(st == ENT_BOX));
+            const uint32_t n_done = (uint32_t)__popcll(__ballot(st == ENT_END));
+            const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
             const uint32_t n_prim = 64u - n_box - n_done - n_idle;
             bool a_has = A.pool_next < A.pool_total;
             if (!a_has) {
                 // retire A once no lane carries one of its paths: write the tile's sums into this batch's partial image
                 // (each pixel of each batch has exactly one writer)
-                if (__ballot(eb.w != ST_IDLE && (slot >> 6) == a_sel) == 0ull) {
+                if (__ballot(st != ST_IDLE && (slot >> 6) == a_sel) == 0ull) {
                     const uint32_t a_tx = A.txy & 0xFFFFu, a_ty = A.txy >> 16;
                     if (a_tx + (lane & 7u) < C.width && a_ty + (lane >> 3) < C.height) {
                         const uint32_t px = a_tx + (lane & 7u), py = a_ty + (lane >> 3);
@@ -611,17 +623,20 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
                 uint32_t nb;
                 RTX_TIC();
+                uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
+                if (st == ENT_BOX) RTX_LOAD_ENTRY(off, ea, eb);
                 do {
 #ifdef RTX_STAGE_COUNTERS
                     sc[0]++;
-                    sc[1] += __popcll(__ballot(eb.w == ENT_BOX));
+                    sc[1] += __popcll(__ballot(st == ENT_BOX));
 #endif
-                    if (eb.w == ENT_BOX) {
+                    if (st == ENT_BOX) {
                         const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, XF ? wx.tmin : tmin, best.t);
                         off = hit ? off + ENT_BYTES : eb.z;
                         RTX_LOAD_ENTRY(off, ea, eb);
+                        st = eb.w;
                     }
-                    nb = (uint32_t)__popcll(__ballot(eb.w == ENT_BOX));
+                    nb = (uint32_t)__popcll(__ballot(st == ENT_BOX));
                 } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
                 RTX_TOC(0);
             } else if (n_prim != 0u && (sc_prim >= sc_serv || n_serv == 0u)) {
@@ -633,9 +648,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                 do {
 #ifdef RTX_STAGE_COUNTERS
                     sc[2]++;
-                    sc[3] += __popcll(__ballot(eb.w - 1u < ENT_END - 1u));
+                    sc[3] += __popcll(__ballot(st - 1u < ENT_END - 1u));
 #endif
-                    if (eb.w - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
+                    if (st - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
+                        uint4 ea, eb;
+                        RTX_LOAD_ENTRY(off, ea, eb);
                         const uint32_t kind = eb.w & 15u;
                         const float lane_tmin = XF ? wx.tmin : tmin;
                         if (XF && kind >= ENT_XF_PUSH) {
@@ -652,9 +669,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                             if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
                             off += ENT_BYTES;
                         }
-                        RTX_LOAD_ENTRY(off, ea, eb);
+                        RTX_LOAD_STATE(off, st);
                     }
-                    np = (uint32_t)__popcll(__ballot(eb.w - 1u < ENT_END - 1u));
+                    np = (uint32_t)__popcll(__ballot(st - 1u < ENT_END - 1u));
                 } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // without instances primitives rarely queue in a row and the loop would cost the lean variant registers
                 RTX_TOC(1);
             } else {
@@ -665,8 +682,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                 sc[5] += n_done;
                 sc[6] += min(n_idle, pool_left);
 #endif
-                if (eb.w == ENT_END) {
-                    eb.w = ST_IDLE;
+                if (st == ENT_END) {
+                    st = ST_IDLE;
                     if (best.ent == NO_HIT) {
                         atomicAdd(&acc[slot * 3 + 0], br * C.background[0]);
                         atomicAdd(&acc[slot * 3 + 1], bg * C.background[1]);
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                 }
                 // ---- service stage 2, ray generation: free lanes take the next (pixel, sample) pairs of the pool
                 //      (camera.rs:147-163)
-                const unsigned long long idle = __ballot(eb.w == ST_IDLE);
+                const unsigned long long idle = __ballot(st == ST_IDLE);
                 if (idle && pool_left != 0u) {
                     // all lanes of one pass draw from one item: A while its pool lasts, then B
                     const uint32_t g_next = a_has ? A.pool_next : B.pool_next, g_total = a_has ? A.pool_total : B.pool_total;
@@ -737,7 +754,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
                     const uint32_t my = g_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     const uint32_t my_slot = my & 63u;
                     const uint32_t x = g_tx + (my_slot & 7u), y = g_ty + (my_slot >> 3);
-                    if (eb.w == ST_IDLE && my < g_total && x < C.width && y < C.height) {
+                    if (st == ST_IDLE && my < g_total && x < C.width && y < C.height) {
                         slot = my_slot | (g_sel << 6);
                         const uint32_t sample = g_s0 + (my >> 6);
                         rng = rng_init(P.seed, y * C.width + x, sample);
@@ -775,6 +792,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 6) void render_ker
     }
 #undef RTX_CLAIM
 #undef RTX_LOAD_ENTRY
+#undef RTX_LOAD_STATE
 #undef RTX_BEGIN_WALK
     // one ray-count update per wave
     for (int o = 32; o > 0; o >>= 1) rays_traced += __shfl_down(rays_traced, o);
@@ -943,7 +961,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
         render_kernel<true, true, true, true>};
     void (*kern)(RenderParams) = kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
-    // Block shape: a block is 4, 8 or 12 waves (1, 2 or 3 per SIMD).  The variant's register count says how many waves a
+    // Block shape: a block is 4, 8, 12 or 16 waves (1 to 4 per SIMD).  The variant's register count says how many waves a
     // SIMD can hold (512 VGPRs each, allocated in eights); take the shape that makes the most waves resident within
     // the 160 KB of LDS, and on a tie the larger block (fewer LDS copies of the entries).
     hipFuncAttributes fa;
@@ -952,7 +970,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     const uint32_t waves_per_simd = std::max(1u, std::min(8u, 512u / ((vgprs + 7u) & ~7u)));
     uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
     size_t lds = 0;
-    for (uint32_t b = 1; b <= 3; b++) {
+    for (uint32_t b = 1; b <= (uint32_t)MAX_WAVES_PER_BLOCK / 4; b++) {
         const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * ACC_FLOATS * sizeof(float);
         const uint32_t fit = (uint32_t)std::min<size_t>(waves_per_simd / b, (160 * 1024) / (l + 2048));
         if (fit * b >= best_resident && fit > 0) {
