@@ -672,7 +672,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         RTX_LOAD_STATE(off, st);
                     }
                     np = (uint32_t)__popcll(__ballot(st - 1u < ENT_END - 1u));
-                } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // without instances primitives rarely queue in a row and the loop would cost the lean variant registers
+                } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // in the lean variant the loop would cost registers, i.e. a resident wave
                 RTX_TOC(1);
             } else {
                 // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
@@ -928,8 +928,8 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     if (P.n_items == 0) return RTX_OK;
     P.rr_start = opts->rr_start_depth;
     P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
-    P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 12));
-    P.w_serv = std::max<uint32_t>(1u, env_u32("RTX_W_SERV", 5));
+    P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 10));
+    P.w_serv = std::max<uint32_t>(1u, env_u32("RTX_W_SERV", 3));
     P.sched_kp = env_u32("RTX_SCHED_KP", 32);
     P.overlap = env_u32("RTX_OVERLAP", 1);
 
