@@ -50,6 +50,7 @@ static_assert(sizeof(Ent) == 32, "entry must be 32 bytes");
 struct Threaded {
     std::vector<Ent> ents;
     std::vector<uint32_t> rank;  // per entry: tie-break rank of a primitive / medium entry (first position in the strict order)
+    std::vector<uint32_t> mat;   // per entry: material of a primitive / medium-end entry (what a hit there is shaded with), else NONE
     uint32_t n_boxes = 0, n_prims = 0;
     bool has_brackets = false;   // contains transform or medium entries
     std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
@@ -196,6 +197,8 @@ class Builder {
     void push_prim(Threaded& out, rtx_ref_t r, uint32_t rank) {
         out.ents.push_back(prim_entry(d, RTX_REF_KIND(r), RTX_REF_INDEX(r)));
         out.rank.push_back(rank);
+        const uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
+        out.mat.push_back(k == RTX_REF_SPHERE ? d.sph_material[i] : k == RTX_REF_QUAD ? d.quad_material[i] : d.tri_material[i]);
         out.n_prims++;
     }
 
@@ -218,12 +221,14 @@ class Builder {
             a.w[7] = ENT_MED_BEGIN | (obj_index << 4);
             out.ents.push_back(a);
             out.rank.push_back(rank);
+            out.mat.push_back(NONE);
             if (!child_fn(o.child, enclosing_xf, xf_depth, true)) return false;
             b.w[6] = at;
             b.w[7] = ENT_MED_END | (obj_index << 4);
             out.ents[at].w[6] = (uint32_t)out.ents.size();
             out.ents.push_back(b);
             out.rank.push_back(rank);
+            out.mat.push_back(o.material);
             out.n_prims++;
         } else {
             if (xf_depth >= MAX_XF_DEPTH) return fail("Translate / RotateY nested deeper than 3 levels", true);
@@ -235,12 +240,14 @@ class Builder {
             a.w[7] = ENT_XF_PUSH | (obj_index << 4);
             out.ents.push_back(a);
             out.rank.push_back(0);
+            out.mat.push_back(NONE);
             if (!child_fn(o.child, at, xf_depth + 1, in_medium)) return false;
             b.w[4] = enclosing_xf;
             b.w[7] = ENT_XF_POP | (obj_index << 4);
             out.ents[at].w[6] = (uint32_t)out.ents.size();
             out.ents.push_back(b);
             out.rank.push_back(0);
+            out.mat.push_back(NONE);
         }
         return true;
     }
@@ -261,6 +268,7 @@ class Builder {
                 uint32_t at = (uint32_t)out.ents.size();
                 out.ents.push_back(box_entry(n.bounds, 0));
                 out.rank.push_back(0);
+                out.mat.push_back(NONE);
                 out.n_boxes++;
                 // a one-element Bvh has left == right (mesh.rs:572-577): the reference tests it twice, so do we
                 ok = emit_strict(out, n.left, enclosing_xf, xf_depth, in_medium) && emit_strict(out, n.right, enclosing_xf, xf_depth, in_medium);
@@ -404,6 +412,7 @@ class Builder {
             const float b6[6] = {u.box.lo[0], u.box.hi[0], u.box.lo[1], u.box.hi[1], u.box.lo[2], u.box.hi[2]};
             out.ents.push_back(box_entry(b6, 0));
             out.rank.push_back(0);
+            out.mat.push_back(NONE);
             out.n_boxes++;
         }
         bool ok = emit_bracketed(out, o, RTX_REF_INDEX(u.ref), u.rank, enclosing_xf, xf_depth, in_medium,
@@ -431,6 +440,7 @@ class Builder {
         const float b6[6] = {bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1], bb.lo[2], bb.hi[2]};
         out.ents.push_back(box_entry(b6, 0));
         out.rank.push_back(0);
+        out.mat.push_back(NONE);
         out.n_boxes++;
 
         int best_axis = -1, best_bin = -1;
@@ -519,8 +529,10 @@ class Reorder {
         old_index.reserve(n);
         dst.ents.clear();
         dst.rank.clear();
+        dst.mat.clear();
         dst.ents.reserve(n + 1);
         dst.rank.reserve(n + 1);
+        dst.mat.reserve(n + 1);
         dst.n_boxes = src.n_boxes;
         dst.n_prims = src.n_prims;
         dst.has_brackets = src.has_brackets;
@@ -563,6 +575,7 @@ class Reorder {
         new_index[i] = p;
         dst.ents.push_back(src.ents[i]);
         dst.rank.push_back(src.rank[i]);
+        dst.mat.push_back(src.mat[i]);
         if (grow_ > 0.0f && src.ents[i].w[7] == ENT_BOX) {
             Ent& e = dst.ents.back();
             for (int a = 0; a < 3; a++) {
@@ -628,6 +641,7 @@ static inline void finalize(Threaded& t) {
     end.w[7] = ENT_END;
     t.ents.push_back(end);
     t.rank.push_back(0);
+    t.mat.push_back(NONE);
 }
 
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.

@@ -57,6 +57,7 @@ struct rtx_scene {
     bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
     bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
     // the fast array in entry-index form and the viewpoint its device copy is currently ordered for
+    std::vector<uint4> mat_recs;  // 2 per material: the shading record a hit entry gets (see DevScene::shade)
     rtx_accel::Threaded fast_indexed;
     float view[3] = {0, 0, 0};
     float view_grow = 0.0f;
@@ -187,6 +188,19 @@ extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal,
     return RTX_OK;
 }
 
+// Per-entry shading records of a threaded array: the record of the entry's material, zeros where nothing can be hit.
+static std::vector<uint4> expand_shade(const rtx_accel::Threaded& t, const std::vector<uint4>& mat_recs) {
+    std::vector<uint4> out(2 * t.ents.size(), make_uint4(0, 0, 0, 0));
+    for (size_t i = 0; i < t.ents.size(); i++) {
+        const uint32_t m = t.mat[i];
+        if (m != rtx_accel::NONE && 2 * (size_t)m + 1 < mat_recs.size()) {
+            out[2 * i] = mat_recs[2 * m];
+            out[2 * i + 1] = mat_recs[2 * m + 1];
+        }
+    }
+    return out;
+}
+
 static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     rtx_accel::Threaded strict, fast;
     std::string err;
@@ -199,12 +213,28 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = prop.multiProcessorCount;
 
+    // shading record per material: kind, flags, parameter, and the colour when the texture is a plain solid one
+    // (the dielectric attenuates with white, material.rs:175)
+    auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    s->mat_recs.assign(2 * (size_t)d->n_materials, make_uint4(0, 0, 0, 0));
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rtx_material_t& m = d->materials[i];
+        const bool glass = m.kind == RTX_MAT_DIELECTRIC;
+        const bool solid = glass || d->textures[m.texture].kind == RTX_TEX_SOLID;
+        const bool uv = !glass && tex_reads_uv(*d, m.texture);
+        const float one[3] = {1.0f, 1.0f, 1.0f};
+        const float* rgb = glass ? one : d->textures[m.texture].rgb;
+        s->mat_recs[2 * i] = make_uint4(m.kind | (solid ? 256u : 0u) | (uv ? 512u : 0u), fbits(m.param), glass ? 0u : m.texture, 0u);
+        s->mat_recs[2 * i + 1] = solid ? make_uint4(fbits(rgb[0]), fbits(rgb[1]), fbits(rgb[2]), 0u) : make_uint4(0, 0, 0, 0);
+    }
+
     const rtx_accel::Threaded* th[2] = {&fast, &strict};
     for (int m = 0; m < 2; m++) {
         const rtx_accel::Ent* ep = nullptr;
         if ((rc = upload(s, th[m]->ents, &ep)) != RTX_OK) return rc;
         s->dev.ents[m] = reinterpret_cast<const uint4*>(ep);
         if ((rc = upload(s, th[m]->rank, &s->dev.rank[m])) != RTX_OK) return rc;
+        if ((rc = upload(s, expand_shade(*th[m], s->mat_recs), &s->dev.shade[m])) != RTX_OK) return rc;
         s->dev.n_ents[m] = s->n_ents[m] = (uint32_t)th[m]->ents.size();  // terminator included
         s->n_boxes[m] = th[m]->n_boxes;
     }
@@ -475,7 +505,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 
     const rtx_camera_t& C = P.cam;
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
-    unsigned long long rays_traced = 0;
+    uint32_t rays_traced = 0;  // per lane; summed in 64 bits at the end
 #ifdef RTX_STAGE_COUNTERS
     unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
     unsigned long long tc[4] = {0, 0, 0, 0};              // wave clocks inside the box / primitive / service stage, and in total
@@ -690,26 +720,21 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
                     } else {
                         HitRec h;
+                        // what the hit is shaded with: one read, indexed like the entries (issued first: it is the long one)
+                        const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.shade[M]) + best.ent);
+                        const uint4 s0 = srec[0], s1 = srec[1];
                         {
                             uint4 ha, hb;
                             RTX_LOAD_ENTRY(best.ent, ha, hb);
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
-                            bool want_uv = false;
-                            if (TEX) {
-                                const uint32_t kind = hb.w & 15u;
-                                if (kind <= ENT_TRI) {
-                                    const uint32_t mat = kind == ENT_SPHERE ? __float_as_uint(S.sph[2 * (hb.w >> 4) + 1].w)
-                                                                            : __float_as_uint(S.planar[5 * ((hb.w >> 4) + (kind == ENT_TRI ? S.n_quads : 0u)) + 1].w);
-                                    want_uv = (S.mats[mat].w & 1u) != 0u;
-                                }
-                            }
+                            const bool want_uv = TEX && (s0.x & 512u) != 0u;
                             if (XF) {
-                                h = TEX && want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
+                                h = want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
                             } else {
-                                h = TEX && want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
+                                h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
                             }
                         }
-                        ScatterOut so = shade<TEX>(S, ray, h, rng);
+                        ScatterOut so = shade<TEX>(S, ray, h, rng, make_uint4(s0.x & 255u, s0.z, s0.y, 0u), (s0.x & 256u) != 0u, as_f(s1.x), as_f(s1.y), as_f(s1.z));
                         if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
                             atomicAdd(&acc[slot * 3 + 0], br * so.er);
                             atomicAdd(&acc[slot * 3 + 1], bg * so.eg);
@@ -795,8 +820,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 #undef RTX_LOAD_STATE
 #undef RTX_BEGIN_WALK
     // one ray-count update per wave
-    for (int o = 32; o > 0; o >>= 1) rays_traced += __shfl_down(rays_traced, o);
-    if (lane == 0 && rays_traced) atomicAdd(P.ray_counter, rays_traced);
+    unsigned long long wave_rays = rays_traced;
+    for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
+    if (lane == 0 && wave_rays) atomicAdd(P.ray_counter, wave_rays);
 #ifdef RTX_STAGE_COUNTERS
     tc[3] = __builtin_readcyclecounter() - t_begin;
     if (lane == 0) {
@@ -855,6 +881,8 @@ static int order_fast_for_view(rtx_scene* scene, const float center[3], float re
     HIP_TRY(hipDeviceSynchronize());  // no walk may be in flight while the array is replaced
     HIP_TRY(hipMemcpy(const_cast<uint4*>(scene->dev.ents[RTX_TRAVERSAL_FAST]), ordered.ents.data(), ordered.ents.size() * sizeof(rtx_accel::Ent), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<uint32_t*>(scene->dev.rank[RTX_TRAVERSAL_FAST]), ordered.rank.data(), ordered.rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const std::vector<uint4> shade = expand_shade(ordered, scene->mat_recs);
+    HIP_TRY(hipMemcpy(const_cast<uint4*>(scene->dev.shade[RTX_TRAVERSAL_FAST]), shade.data(), shade.size() * sizeof(uint4), hipMemcpyHostToDevice));
     std::memcpy(scene->view, center, sizeof(scene->view));
     scene->view_grow = grow;
     scene->view_valid = true;

@@ -28,6 +28,9 @@ struct DevImage {
 struct DevScene {
     const uint4* ents[2];      // [RTX_TRAVERSAL_FAST], [RTX_TRAVERSAL_STRICT]: 2 x uint4 per entry
     const uint32_t* rank[2];   // per entry tie-break rank
+    const uint4* shade[2];     // per entry, 2 x uint4: what a hit at that entry is shaded with, resolved on the host:
+                               //   (material kind | 256 if the colour below is final | 512 if the texture reads uv,
+                               //    param bits, texture, 0) (r, g, b bits, 0)
     uint32_t n_ents[2];
     const float4* sph;         // 2 per sphere: (c0.xyz, r) (dc.xyz, material bits)
     const uint32_t* sph_id;
@@ -633,14 +636,16 @@ struct ScatterOut {
 // Every scatter consumes exactly two draws of the path's stream (the dielectric uses the first as its xi).
 // Shading arithmetic only has to agree with the reference within tolerance (the streams differ anyway), so this
 // function may fuse multiply-adds and uses the hardware reciprocal / reciprocal square root.
+// `m` = (kind, texture, param bits, flags) as in DevScene::mats.  With `solid` the texture colour is already known
+// (rgb): the common case of a solid colour needs no dependent table reads at all.
 template <bool FULL>
-__device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitRec& h, Rng& rng) {
+__device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitRec& h, Rng& rng, const uint4 m, const bool solid, const float sr,
+                                   const float sg, const float sb) {
 #pragma clang fp contract(fast)
     ScatterOut o;
     o.scattered = false;
     o.ar = o.ag = o.ab = 0.0f;
     o.er = o.eg = o.eb = 0.0f;
-    const uint4 m = S.mats[h.mat];
     o.ray.ox = h.px;
     o.ray.oy = h.py;
     o.ray.oz = h.pz;
@@ -649,11 +654,11 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
     const float u1 = rng_f32(rng);
     const float u2 = rng_f32(rng);
     const float rz = 1.0f - 2.0f * u1;
-    const float rr = __builtin_sqrtf(fmaxf(0.0f, 1.0f - rz * rz));
+    const float rr = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - rz * rz));
     const float rx = rr * __builtin_amdgcn_cosf(u2);
     const float ry = rr * __builtin_amdgcn_sinf(u2);
-    float tr = 1.0f, tg = 1.0f, tb = 1.0f;
-    if (m.x != RTX_MAT_DIELECTRIC) tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, tr, tg, tb);
+    float tr = sr, tg = sg, tb = sb;
+    if (!solid) tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, tr, tg, tb);
     float dx = 0.0f, dy = 0.0f, dz = 0.0f;
     if (m.x == RTX_MAT_LAMBERTIAN) {
         dx = h.nx + rx;
@@ -681,7 +686,7 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
         const float ux = rin.dx * inv_len, uy = rin.dy * inv_len, uz = rin.dz * inv_len;
         const float udn = dot3(ux, uy, uz, h.nx, h.ny, h.nz);
         const float cos_theta = -fminf(udn, 1.0f);
-        const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        const float sin_theta = __builtin_amdgcn_sqrtf(1.0f - cos_theta * cos_theta);
         const bool cannot_refract = ri * sin_theta > 1.0f;
         if (cannot_refract || reflectance(cos_theta, ri) > u1) {
             const float k = 2.0f * udn;
@@ -690,7 +695,7 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
             dz = uz - k * h.nz;
         } else {  // refract (material.rs:23-28)
             const float ppx = ri * (ux + cos_theta * h.nx), ppy = ri * (uy + cos_theta * h.ny), ppz = ri * (uz + cos_theta * h.nz);
-            const float par = -__builtin_sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
+            const float par = -__builtin_amdgcn_sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
             dx = ppx + par * h.nx;
             dy = ppy + par * h.ny;
             dz = ppz + par * h.nz;
