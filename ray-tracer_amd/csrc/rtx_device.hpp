@@ -85,7 +85,7 @@ __device__ __forceinline__ void random_unit_vec(Rng& r, float& x, float& y, floa
     float u1 = rng_f32(r);
     float u2 = rng_f32(r);
     z = 1.0f - 2.0f * u1;
-    float rr = __builtin_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float rr = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - z * z));  // samplers need no correctly rounded root
     x = rr * __builtin_amdgcn_cosf(u2);  // hardware cos takes revolutions: cos(2*pi*u2)
     y = rr * __builtin_amdgcn_sinf(u2);
 }
@@ -93,7 +93,7 @@ __device__ __forceinline__ void random_unit_vec(Rng& r, float& x, float& y, floa
 __device__ __forceinline__ void random_in_unit_disk(Rng& r, float& x, float& y) {
     float u1 = rng_f32(r);
     float u2 = rng_f32(r);
-    float rr = __builtin_sqrtf(u1);
+    float rr = __builtin_amdgcn_sqrtf(u1);
     x = rr * __builtin_amdgcn_cosf(u2);
     y = rr * __builtin_amdgcn_sinf(u2);
 }
