@@ -712,6 +712,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 sc[5] += n_done;
                 sc[6] += min(n_idle, pool_left);
 #endif
+                bool begin_walk = false;  // scattered and newly generated rays start their walk together, below
                 if (st == ENT_END) {
                     st = ST_IDLE;
                     if (best.ent == NO_HIT) {
@@ -762,7 +763,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                             }
                             if (alive) {
                                 ray = so.ray;
-                                RTX_BEGIN_WALK();
+                                st = root_st;  // no longer free: ray generation below must not take this lane
+                                begin_walk = true;
                             }
                         }
                     }
@@ -806,11 +808,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         br = bg = bb = 1.0f;
                         depth_left = C.max_depth;
                         // ray_color(depth 0) is black before any hit test (camera.rs:125): the lane stays free
-                        if (depth_left != 0) RTX_BEGIN_WALK();
+                        begin_walk = depth_left != 0;
                     }
                     const uint32_t g_adv = min(g_total, g_next + (uint32_t)__popcll(idle));
                     if (a_has) A.pool_next = g_adv; else B.pool_next = g_adv;
                 }
+                if (begin_walk) RTX_BEGIN_WALK();
                 RTX_TOC(2);
             }
         }
