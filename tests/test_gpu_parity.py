@@ -320,6 +320,46 @@ def test_invalid_arguments_are_rejected(render, scenes):
         scene.trace(np.zeros(1, dtype=importlib.import_module("ray-tracer_amd.capi").RAY_DTYPE), traversal=7)
 
 
+def test_empty_single_and_degenerate_inputs(render, oracle, scene):
+    """Edges of the input space: no rays, a one-primitive Bvh (its only child is tested twice, mesh.rs:572-577), rays
+    with zero or non-finite components, empty sample ranges."""
+    import torch
+
+    capi = importlib.import_module("ray-tracer_amd.capi")
+    w = scene.World()
+    w.push(scene.Sphere.stationary((0, 0, -3), 1.0, scene.Metal.rgb(.8, .8, .8).with_roughness(0.1)))
+    bvh = scene.Bvh(w)
+    om, gs = oracle.OracleMesh(bvh), render.Scene(bvh)
+    assert len(gs.trace(np.zeros(0, dtype=capi.RAY_DTYPE))) == 0
+    rays = np.zeros(7, dtype=capi.RAY_DTYPE)
+    rays["o"] = [(0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, -3), (5, 0, 0), (0, 0, 0), (0, 0, 0)]
+    rays["d"] = [(0, 0, -1), (0, 0, 1), (0, 0, 0), (0, 1, 0), (0, 0, -1), (0, 0, -1e-30), (0, 0, -1e30)]
+    rays["time"] = 0.25
+    want = om.trace(rays)
+    for mode in (render.TRAVERSAL_STRICT, render.TRAVERSAL_FAST):
+        got = gs.trace(rays, traversal=mode)
+        assert np.array_equal(got["prim_id"], want["prim_id"]), mode
+        hit = want["prim_id"] != MISS
+        assert np.array_equal(got["t"][hit], want["t"][hit])
+    assert want["prim_id"][0] == 0 and want["prim_id"][1] == MISS and want["prim_id"][3] == 0 and want["prim_id"][4] == MISS
+    inf_rays = np.zeros(2, dtype=capi.RAY_DTYPE)
+    inf_rays["d"] = [(np.nan, 0, -1), (0, np.inf, -1)]
+    got = gs.trace(inf_rays, traversal=render.TRAVERSAL_FAST)  # no hang, no fault; the reference's answer for these is a miss too
+    assert np.array_equal(got["prim_id"], om.trace(inf_rays)["prim_id"])
+    # empty sample ranges leave the buffer alone; a one-primitive scene renders
+    cfg = importlib.import_module("ray-tracer_amd.scenes").CAMERAS["default"]().replace(width=24, height=16, samples_per_pixel=4)
+    cam = render.Camera(cfg)
+    buf = torch.full((24 * 16 * 3,), 7.0, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cam.render_accumulate(gs, buf.data_ptr(), 2, 2, seed=1, stream=st)
+    torch.cuda.synchronize()
+    assert bool((buf == 7.0).all())
+    with pytest.raises(render.RtxError):
+        cam.render_accumulate(gs, buf.data_ptr(), 3, 2, seed=1, stream=st)
+    rgb = cam.render(gs, seed=1)
+    assert rgb.shape == (16, 24, 3)
+
+
 INSTANCED = [("cornell-box", 0, 200, 200), ("cornell-smoke", 0, 200, 200), ("final-scene", 1, 200, 200)]
 
 
