@@ -81,3 +81,29 @@ def test_cli_renders_a_png(tmp_path):
     want = render.Camera(cfg).render(render.Scene(world), seed=5)
     assert np.array_equal(img, want)
     assert img.std() > 10  # five coloured quads, not a blank frame
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["spp", "tile"])
+def test_bench_two_ranks_render_the_single_rank_frame(tmp_path, split):
+    """bench.py end to end with two processes (both on GPU 0, gloo standing in for RCCL): the reduced frame is the
+    single-process frame up to the order of fp32 additions, and the JSON line carries the contract fields."""
+    import json
+
+    common = ["--spp", "32", "--width", "320", "--height", "180", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    one = tmp_path / "one.png"
+    out1 = subprocess.check_output([sys.executable, "bench.py", "--gpus", "1", "--save", str(one)] + common, cwd=ROOT, timeout=300)
+    two = tmp_path / "two.png"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out2 = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                    "--master-port", "29533" if split == "spp" else "29534", "bench.py", "--gpus", "2", "--backend", "gloo", "--one-device",
+                                    "--split", split, "--save", str(two)] + common, cwd=ROOT, timeout=600, env=env)
+    a, b = png.decode_rgb8(one.read_bytes()), png.decode_rgb8(two.read_bytes())
+    assert a.shape == b.shape == (180, 320, 3)
+    diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 0.01
+    for raw, n in ((out1, 1), (out2, 2)):
+        line = [l for l in raw.decode().splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == n and d["unit"] == "Msamples/s" and d["value"] > 0 and d["scaling"] == "strong"
+        assert d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
