@@ -54,6 +54,7 @@ struct rtx_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 0;
     float coord_range = 0.0f;    // largest |coordinate| the fast boxes were padded for
+    uint32_t n_perlins = 0;
     bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
     bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
     // the fast array in entry-index form and the viewpoint its device copy is currently ordered for
@@ -325,6 +326,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         std::memcpy(dst + 1280, p.perm_z, 256 * 4);
     }
     if ((rc = upload(s, perlin, &s->dev.perlin)) != RTX_OK) return rc;
+    s->n_perlins = d->n_perlins;
 
     HIP_TRY(hipMalloc((void**)&s->counters, 128));
     HIP_TRY(hipEventCreate(&s->ev0));
@@ -465,6 +467,7 @@ struct RenderParams {
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
     uint32_t sched_kp;    // primitive stage keeps running while n_prim * sched_kp >= 8 * lanes queued elsewhere (0 = one step)
+    uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
     uint32_t overlap;     // 1: free lanes start on the wave's next item while the current one drains
     uint32_t* item_counter;
     unsigned long long* ray_counter;
@@ -500,8 +503,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * (2 * ACC_FLOATS);
     if (ENTS_IN_LDS) {
         for (uint32_t i = threadIdx.x; i < ent_u4; i += blockDim.x) smem[i] = gents[i];
-        __syncthreads();
     }
+    // TEX: Perlin table set 0 (6 KB) behind the accumulators when the launch reserved room for it
+    uint32_t lds_perlin = 0xFFFFFFFFu;
+    if (TEX && P.perlin_in_lds != 0u) {
+        const uint32_t at_u4 = ent_u4 + (blockDim.x >> 6) * (2 * ACC_FLOATS / 4);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S.perlin);
+        for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += blockDim.x) smem[at_u4 + i] = src[i];
+        lds_perlin = at_u4 * 16u;
+    }
+    if (ENTS_IN_LDS || TEX) __syncthreads();
 
     const rtx_camera_t& C = P.cam;
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                                 h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
                             }
                         }
-                        ScatterOut so = shade<TEX>(S, ray, h, rng, make_uint4(s0.x & 255u, s0.z, s0.y, 0u), (s0.x & 256u) != 0u, as_f(s1.x), as_f(s1.y), as_f(s1.z));
+                        ScatterOut so = shade<TEX>(S, ray, h, rng, make_uint4(s0.x & 255u, s0.z, s0.y, 0u), (s0.x & 256u) != 0u, as_f(s1.x), as_f(s1.y), as_f(s1.z), lds_perlin);
                         if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
                             atomicAdd(&acc[slot * 3 + 0], br * so.er);
                             atomicAdd(&acc[slot * 3 + 1], bg * so.eg);
@@ -992,6 +1003,9 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
         render_kernel<true, true, true, true>};
     void (*kern)(RenderParams) = kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
+    // noise textures read their tables 336 times per value: table set 0 goes to LDS (6 KB per block)
+    const size_t perlin_lds = scene->has_tex && scene->n_perlins != 0 && env_u32("RTX_PERLIN_LDS", 1) != 0u ? 1536 * sizeof(float) : 0;
+    P.perlin_in_lds = perlin_lds != 0 ? 1u : 0u;
     // Block shape: a block is 4, 8, 12 or 16 waves (1 to 4 per SIMD).  The variant's register count says how many waves a
     // SIMD can hold (512 VGPRs each, allocated in eights); take the shape that makes the most waves resident within
     // the 160 KB of LDS, and on a tie the larger block (fewer LDS copies of the entries).
@@ -1002,7 +1016,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
     size_t lds = 0;
     for (uint32_t b = 1; b <= (uint32_t)MAX_WAVES_PER_BLOCK / 4; b++) {
-        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * ACC_FLOATS * sizeof(float);
+        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * ACC_FLOATS * sizeof(float) + perlin_lds;
         const uint32_t fit = (uint32_t)std::min<size_t>(waves_per_simd / b, (160 * 1024) / (l + 2048));
         if (fit * b >= best_resident && fit > 0) {
             best_resident = fit * b;
@@ -1014,7 +1028,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     if (best_resident == 0) return fail(RTX_ERR_DEVICE, "internal: no block shape fits");
     wpb = std::min<uint32_t>(MAX_WAVES_PER_BLOCK, std::max<uint32_t>(4u, env_u32("RTX_WAVES_PER_BLOCK", wpb) & ~3u));
     blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", blocks_per_cu);
-    lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * 2 * ACC_FLOATS * sizeof(float);
+    lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * 2 * ACC_FLOATS * sizeof(float) + perlin_lds;
     dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
     if (env_u32("RTX_DEBUG", 0))
         std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u batches of %u spp, %u items\n", vgprs, wpb,

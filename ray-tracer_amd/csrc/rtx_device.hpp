@@ -537,8 +537,9 @@ __device__ __forceinline__ float clamp01(float v) {  // Interval(0..1).clamp (li
 }
 
 // Perlin::noise / perlin_interp / turb (texture.rs:187-243)
-__device__ inline float perlin_noise(const float* __restrict__ tab, float px, float py, float pz) {
-    const uint32_t* perm = reinterpret_cast<const uint32_t*>(tab + 768);
+// TAB is a pointer to one table set (768 floats, then 3 * 256 permutation words) in device memory or in LDS.
+template <class TAB>
+__device__ inline float perlin_noise(TAB tab, float px, float py, float pz) {
     float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
     float u = px - fx, v = py - fy, w = pz - fz;
     int32_t i = as_i32_sat(fx), j = as_i32_sat(fy), k = as_i32_sat(fz);
@@ -554,7 +555,8 @@ __device__ inline float perlin_noise(const float* __restrict__ tab, float px, fl
         for (int dj = 0; dj < 2; dj++)
 #pragma unroll
             for (int dk = 0; dk < 2; dk++) {
-                uint32_t g = perm[(uint32_t)(i + di) & 255u] ^ perm[256 + ((uint32_t)(j + dj) & 255u)] ^ perm[512 + ((uint32_t)(k + dk) & 255u)];
+                uint32_t g = __float_as_uint(tab[768 + ((uint32_t)(i + di) & 255u)]) ^ __float_as_uint(tab[1024 + ((uint32_t)(j + dj) & 255u)]) ^
+                             __float_as_uint(tab[1280 + ((uint32_t)(k + dk) & 255u)]);
                 float cx = tab[3 * g], cy = tab[3 * g + 1], cz = tab[3 * g + 2];
                 float fi = (float)di, fj = (float)dj, fk = (float)dk;
                 accum += (fi * uu + (1.0f - fi) * (1.0f - uu)) * (fj * vv + (1.0f - fj) * (1.0f - vv)) * (fk * ww + (1.0f - fk) * (1.0f - ww)) *
@@ -562,7 +564,8 @@ __device__ inline float perlin_noise(const float* __restrict__ tab, float px, fl
             }
     return accum;
 }
-__device__ inline float perlin_turb(const float* __restrict__ tab, float px, float py, float pz, int depth) {
+template <class TAB>
+__device__ inline float perlin_turb(TAB tab, float px, float py, float pz, int depth) {
     float accum = 0.0f, weight = 1.0f;
     for (int n = 0; n < depth; n++) {
         accum += weight * perlin_noise(tab, px, py, pz);
@@ -575,8 +578,10 @@ __device__ inline float perlin_turb(const float* __restrict__ tab, float px, flo
 }
 
 // Texture::value (texture.rs:34-37, :63-74, :100-114, :132-137)
+// lds_perlin: LDS byte address of a copy of Perlin table set 0, or 0xFFFFFFFF when the block keeps none.
 template <bool FULL>
-__device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float v, float px, float py, float pz, float& r, float& g, float& b) {
+__device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float v, float px, float py, float pz, float& r, float& g, float& b,
+                                 uint32_t lds_perlin = 0xFFFFFFFFu) {
     uint4 t0 = S.texs[2 * tex];
     for (int guard = 0; guard < 16 && t0.x == RTX_TEX_CHECKER; guard++) {
         float scale = as_f(t0.y);
@@ -604,8 +609,13 @@ __device__ inline void tex_value(const DevScene& S, uint32_t tex, float u, float
         g = (float)px8[1] * color_scale;
         b = (float)px8[2] * color_scale;
     } else if (FULL && t0.x == RTX_TEX_NOISE) {
-        const float* tab = S.perlin + (size_t)t0.z * 1536;
-        float s = 1.0f + sinf(as_f(t0.y) * pz + 10.0f * perlin_turb(tab, px, py, pz, 7));
+        float turb;
+        if (t0.z == 0u && lds_perlin != 0xFFFFFFFFu) {  // 336 table reads per value: from LDS when the table is there
+            turb = perlin_turb((__attribute__((address_space(3))) const float*)(uintptr_t)lds_perlin, px, py, pz, 7);
+        } else {
+            turb = perlin_turb(S.perlin + (size_t)t0.z * 1536, px, py, pz, 7);
+        }
+        float s = 1.0f + sinf(as_f(t0.y) * pz + 10.0f * turb);
         r = g = b = (1.0f * 0.5f) * s;
     } else {
         r = g = b = 0.0f;
@@ -640,7 +650,7 @@ struct ScatterOut {
 // (rgb): the common case of a solid colour needs no dependent table reads at all.
 template <bool FULL>
 __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitRec& h, Rng& rng, const uint4 m, const bool solid, const float sr,
-                                   const float sg, const float sb) {
+                                   const float sg, const float sb, const uint32_t lds_perlin = 0xFFFFFFFFu) {
 #pragma clang fp contract(fast)
     ScatterOut o;
     o.scattered = false;
@@ -658,7 +668,7 @@ __device__ inline ScatterOut shade(const DevScene& S, const Ray& rin, const HitR
     const float rx = rr * __builtin_amdgcn_cosf(u2);
     const float ry = rr * __builtin_amdgcn_sinf(u2);
     float tr = sr, tg = sg, tb = sb;
-    if (!solid) tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, tr, tg, tb);
+    if (!solid) tex_value<FULL>(S, m.y, h.u, h.v, h.px, h.py, h.pz, tr, tg, tb, lds_perlin);
     float dx = 0.0f, dy = 0.0f, dz = 0.0f;
     if (m.x == RTX_MAT_LAMBERTIAN) {
         dx = h.nx + rx;
