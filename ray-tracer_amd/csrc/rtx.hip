@@ -227,6 +227,17 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         const float* rgb = glass ? one : d->textures[m.texture].rgb;
         s->mat_recs[2 * i] = make_uint4(m.kind | (solid ? 256u : 0u) | (uv ? 512u : 0u), fbits(m.param), glass ? 0u : m.texture, 0u);
         s->mat_recs[2 * i + 1] = solid ? make_uint4(fbits(rgb[0]), fbits(rgb[1]), fbits(rgb[2]), 0u) : make_uint4(0, 0, 0, 0);
+        // a checker of two plain colours on a material without a parameter: scale and both colours fit the record
+        // (1024: word 1 = scale, words 2-4 = even colour, words 5-7 = odd colour)
+        if (!glass && m.kind != RTX_MAT_METAL && d->textures[m.texture].kind == RTX_TEX_CHECKER) {
+            const rtx_texture_t& c = d->textures[m.texture];
+            if (d->textures[c.a].kind == RTX_TEX_SOLID && d->textures[c.b].kind == RTX_TEX_SOLID) {
+                const float* e = d->textures[c.a].rgb;
+                const float* o = d->textures[c.b].rgb;
+                s->mat_recs[2 * i] = make_uint4(m.kind | 1024u, fbits(c.scale), fbits(e[0]), fbits(e[1]));
+                s->mat_recs[2 * i + 1] = make_uint4(fbits(e[2]), fbits(o[0]), fbits(o[1]), fbits(o[2]));
+            }
+        }
     }
 
     const rtx_accel::Threaded* th[2] = {&fast, &strict};
@@ -746,7 +757,22 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                                 h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
                             }
                         }
-                        ScatterOut so = shade<TEX>(S, ray, h, rng, make_uint4(s0.x & 255u, s0.z, s0.y, 0u), (s0.x & 256u) != 0u, as_f(s1.x), as_f(s1.y), as_f(s1.z), lds_perlin);
+                        uint4 mrec = make_uint4(s0.x & 255u, s0.z, s0.y, 0u);
+                        bool solid = (s0.x & 256u) != 0u;
+                        float cr = as_f(s1.x), cg = as_f(s1.y), cb = as_f(s1.z);
+                        if ((s0.x & 1024u) != 0u) {
+                            // CheckerTexture::value (texture.rs:63-74) of two solid colours, all of it in the record
+                            const float scale = as_f(s0.y);
+                            const int32_t cx = as_i32_sat(floorf(h.px * scale)), cy = as_i32_sat(floorf(h.py * scale)), cz = as_i32_sat(floorf(h.pz * scale));
+                            const bool even = ((int32_t)((uint32_t)cx + (uint32_t)cy + (uint32_t)cz)) % 2 == 0;
+                            cr = even ? as_f(s0.z) : as_f(s1.y);
+                            cg = even ? as_f(s0.w) : as_f(s1.z);
+                            cb = even ? as_f(s1.x) : as_f(s1.w);
+                            mrec.y = 0u;
+                            mrec.z = 0u;
+                            solid = true;
+                        }
+                        ScatterOut so = shade<TEX>(S, ray, h, rng, mrec, solid, cr, cg, cb, lds_perlin);
                         if (so.er != 0.0f || so.eg != 0.0f || so.eb != 0.0f) {
                             atomicAdd(&acc[slot * 3 + 0], br * so.er);
                             atomicAdd(&acc[slot * 3 + 1], bg * so.eg);

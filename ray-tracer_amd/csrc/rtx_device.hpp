@@ -31,6 +31,8 @@ struct DevScene {
     const uint4* shade[2];     // per entry, 2 x uint4: what a hit at that entry is shaded with, resolved on the host:
                                //   (material kind | 256 if the colour below is final | 512 if the texture reads uv,
                                //    param bits, texture, 0) (r, g, b bits, 0)
+                               //   or, with 1024 set (checker of two plain colours, material without a parameter):
+                               //   (kind | 1024, scale bits, even r, even g) (even b, odd r, odd g, odd b)
     uint32_t n_ents[2];
     const float4* sph;         // 2 per sphere: (c0.xyz, r) (dc.xyz, material bits)
     const uint32_t* sph_id;
