@@ -46,27 +46,44 @@ FLOPS = {
 }
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
-# What the kernel itself executes per ray on the default workload, from the build with stage counters
-# (profiles/r1_stage_counters.txt): its SAH tree needs far fewer tests than the reference's tree.
-OWN_TESTS_PER_RAY = {"node_tests": 24.04, "sphere_tests": 2.11}
+HBM_PEAK_TBS = 8.0
 
 
 def measured_hbm_traffic(workload_is_default):
-    """HBM bytes of one render_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-    collected in separate runs; FETCH_SIZE counts 64 B per 128-B request on gfx950 and is doubled)."""
-    path = os.path.join(ROOT, "profiles", "r1_final_hbm_counters.csv")
-    if not workload_is_default or not os.path.exists(path):
-        return None
+    """(bytes, file) -- HBM bytes of one render_kernel launch of the default workload from the newest committed
+    rocprofv3 PMC passes under profiles/ (FETCH_SIZE and WRITE_SIZE are collected in separate runs; FETCH_SIZE counts
+    64 B per 128-B request on gfx950 and is doubled).  A PMC pass cannot run inside this process, so this is the one
+    figure of the line that is not measured live; the file it came from is named beside it."""
     import csv
+    import glob
 
-    kb = {}
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            if "render_kernel" in row["Kernel_Name"]:
-                kb[row["Counter_Name"]] = float(row["Counter_Value"])
-    if "FETCH_SIZE" not in kb or "WRITE_SIZE" not in kb:
-        return None
-    return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024)
+    if not workload_is_default:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.csv")), reverse=True):
+        kb = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if "render_kernel" in row["Kernel_Name"]:
+                    kb[row["Counter_Name"]] = float(row["Counter_Value"])
+        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+            return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run from
+    this process, which has not touched the GPU, and pass on rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -89,7 +106,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--mesh-nlat", type=int, default=0, help="triangle-mesh / mixed scenes: latitude rings of the synthetic mesh (500 = 998k triangles)")
     ap.add_argument("--save", default=None, help="write the frame to this PNG (rank 0)")
+    ap.add_argument("--in-library", action="store_true",
+                    help="multi-GPU through the C ABI instead of one process per GPU: ONE process, rtx_render_multi drives --gpus devices")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_library:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))  # before anything touches the GPU
 
     import numpy as np
     import torch
@@ -97,6 +119,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.in_library:
+        return in_library(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     if args.one_device:
@@ -130,7 +154,7 @@ def main():
         begin, end, tile_rank, tile_world = 0, args.spp, rank, world
     else:
         (begin, end), tile_rank, tile_world = parallel.sample_range(args.spp, rank, world), 0, 1
-    kernel_ms, rays = [], []
+    kernel_ms, rays, box_tests, prim_tests, flags = [], [], [], [], []
 
     def step(record):
         accum.zero_()
@@ -144,6 +168,9 @@ def main():
         if record:
             kernel_ms.append(st.kernel_ms)
             rays.append(st.rays)
+            box_tests.append(st.box_tests)
+            prim_tests.append(st.prim_tests)
+            flags.append(st.flags)
 
     def fence():
         torch.cuda.synchronize()
@@ -160,105 +187,170 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, float(sum(rays))], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, float(sum(rays)), float(sum(box_tests)), float(sum(prim_tests))], device="cuda", dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-        total_rays = float(t[1])
+        total_rays, total_box, total_prim = float(t[1]), float(t[2]), float(t[3])
     else:
-        total_rays = float(sum(rays))
+        total_rays, total_box, total_prim = float(sum(rays)), float(sum(box_tests)), float(sum(prim_tests))
 
     if rank == 0:
-        samples_per_step = cfg.width * cfg.height * args.spp
-        value = samples_per_step * args.steps / elapsed / 1e6
-        out = {
-            "metric": "Msamples/sec (whole node) at 1920x1080, depth 50",
-            "value": round(value, 2),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.scene} seed {args.seed} ({scene.n_prims} primitives), "
-                                   f"{cfg.width}x{cfg.height}, {args.spp} spp, depth {args.depth}",
-                       "traversal": args.traversal, "russian_roulette_start": args.rr,
-                       "parallelism": f"{args.split}-split x{world} + {'RCCL' if args.backend == 'nccl' else args.backend} reduce" if world > 1 else "single GPU"},
-            "mrays_per_s": round(total_rays / elapsed / 1e6, 1),
-            "rays_per_sample": round(total_rays / (samples_per_step * args.steps), 3),
-            "kernel_ms": round(float(np.mean(kernel_ms)), 3),  # rank 0's render_kernel, HIP events on the launch stream
-        }
+        parallelism = f"{args.split}-split x{world}, one process per GPU + {'RCCL' if args.backend == 'nccl' else args.backend} reduce" if world > 1 else "single GPU"
+        out = result_line(args, cfg, scene.n_prims, world, elapsed, total_rays, total_box, total_prim, float(np.mean(kernel_ms)), parallelism)
         if args.save:
             from PIL import Image
 
             Image.fromarray(rgb.cpu().numpy().reshape(cfg.height, cfg.width, 3)).save(args.save)
-
-        if world == 1 and not args.no_cpu:
-            # CPU baseline + work counts: the oracle renders a bounded sample of the same frame on this box's cores
-            from oracle import binding as ob
-
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
-            ccfg = cfg.replace(samples_per_pixel=args.cpu_spp)
-            om, oc = ob.OracleMesh(bvh), ob.OracleCamera(ccfg)
-            ob.counters_reset()
+        if world == 1:
+            # the same frame through rtx_render with host buffers: scene resident, image (and nothing else) over PCIe
             t1 = time.perf_counter()
-            oc.render(om, seed=args.seed, rng_kind=0, threads=cores, want_rgb=False)
-            cpu_s = time.perf_counter() - t1
-            cnt = ob.counters()
-            cpu_samples = cfg.width * cfg.height * args.cpu_spp
-            flops_per_sample = sum(FLOPS[k] * cnt[k] for k in FLOPS) / cnt["samples"]
-            out["cpu_baseline"] = {
-                "value": round(cpu_samples / cpu_s / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                "sample": f"same scene and camera, {cfg.width}x{cfg.height} at {args.cpu_spp} spp ({cpu_samples / 1e6:.1f} Msamples, "
-                          f"{cpu_s:.1f} s): C++ restatement of the reference CPU renderer (pointer-tree BVH, virtual dispatch, "
-                          f"ChaCha12 + rejection samplers), not the Rust binary",
-                "rays_per_sample": round(cnt["rays"] / cnt["samples"], 3),
-                "node_tests_per_ray": round(cnt["node_tests"] / cnt["rays"], 2),
-                "sphere_tests_per_ray": round(cnt["sphere_tests"] / cnt["rays"], 2),
-            }
-            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-            ms = float(np.mean(kernel_ms))
-            flops_per_launch = flops_per_sample * samples_per_step
-            achieved = flops_per_launch / (ms * 1e-3) / 1e12
-            default_workload = (args.scene, args.seed, args.width, args.height, args.spp, args.depth, args.traversal, args.rr) == \
-                ("bouncing-spheres", 1, 1920, 1080, 1000, 50, "fast", 0)
-            ref_work = {
-                "flops_per_sample": round(flops_per_sample, 1), "achieved": round(achieved, 3), "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4),
-                "note": "f32 operations the REFERENCE performs for these samples (instrumented oracle; its loose origin-including "
-                        "boxes make it test ~110 nodes and ~75 spheres per ray) / kernel time: work delivered, which can exceed "
-                        "the peak because the kernel reaches the same hits with far fewer tests",
-            }
-            out["roofline"] = {"bound": "valu", "kernel": "render_kernel", "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "traffic": measured_hbm_traffic(default_workload), "kernel_ms": round(ms, 3)}
-            if default_workload:
-                # the kernel's own algorithm, same per-event costs: the operations its walk needs for these samples
-                rps = total_rays / (samples_per_step * args.steps)
-                own = dict(cnt)
-                own["node_tests"] = OWN_TESTS_PER_RAY["node_tests"] * rps * cnt["samples"]
-                own["sphere_tests"] = OWN_TESTS_PER_RAY["sphere_tests"] * rps * cnt["samples"]
-                own_fps = sum(FLOPS[k] * own[k] for k in FLOPS) / cnt["samples"]
-                own_tf = own_fps * samples_per_step / (ms * 1e-3) / 1e12
-                out["roofline"].update({
-                    "achieved": round(own_tf, 3), "frac": round(own_tf / FP32_VECTOR_PEAK_TFLOPS, 4),
-                    "algorithmic_flops_per_sample": round(own_fps, 1),
-                    "note": "algorithmic work of the kernel's own walk: 24.0 box + 2.1 sphere tests per ray (stage-counter build, "
-                            "profiles/r1_stage_counters.txt) and the reference's shading, at the reference's per-event costs. The "
-                            "kernel issues 0.72 G vector instructions/s per SIMD (the measured issue ceiling of this instruction mix) "
-                            "at 58% active lanes; most of a box test is min/max/compare, not FMA",
-                    "reference_work": ref_work,
-                })
-            else:
-                out["roofline"].update({"achieved": ref_work["achieved"], "frac": ref_work["frac"],
-                                        "algorithmic_flops_per_sample": ref_work["flops_per_sample"], "note": ref_work["note"]})
+            cam.render(scene, seed=args.seed, traversal=trav, rr_start_depth=args.rr)
+            dt = time.perf_counter() - t1
+            out["pcie_inclusive"] = {"value": round(cfg.width * cfg.height * args.spp / dt / 1e6, 2), "unit": "Msamples/s", "ms": round(dt * 1e3, 3),
+                                     "note": "one rtx_render call with host buffers: device allocation, render, resolve, RGB8 copied to the host"}
+        if world == 1 and not args.no_cpu:
+            cpu_and_roofline(out, args, cfg, bvh, scene, float(np.mean(kernel_ms)), total_rays, total_box, total_prim, bool(flags[-1] & 1))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def result_line(args, cfg, n_prims, n_gpus, elapsed, total_rays, total_box, total_prim, kernel_ms, parallelism):
+    samples_per_step = cfg.width * cfg.height * args.spp
+    return {
+        "metric": "Msamples/sec (whole node) at 1920x1080, depth 50",
+        "value": round(samples_per_step * args.steps / elapsed / 1e6, 2),
+        "unit": "Msamples/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.scene} seed {args.seed} ({n_prims} primitives), "
+                               f"{cfg.width}x{cfg.height}, {args.spp} spp, depth {args.depth}",
+                   "traversal": args.traversal, "russian_roulette_start": args.rr, "parallelism": parallelism},
+        "mrays_per_s": round(total_rays / elapsed / 1e6, 1),
+        "rays_per_sample": round(total_rays / (samples_per_step * args.steps), 3),
+        # counted by the kernel itself in this run (lanes x steps of its box / primitive stages)
+        "box_tests_per_ray": round(total_box / max(total_rays, 1.0), 3),
+        "prim_tests_per_ray": round(total_prim / max(total_rays, 1.0), 3),
+        "kernel_ms": round(kernel_ms, 3),  # render_kernel, HIP events on the launch stream (rank 0 / slowest device)
+    }
+
+
+def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_box, total_prim, entries_in_lds):
+    """CPU baseline (the oracle timed on this box's cores on a bounded sample of the same frame) and the roofline of the
+    dominant kernel from this run's own counts."""
+    from oracle import binding as ob
+
+    samples_per_step = cfg.width * cfg.height * args.spp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    # event counts per sample (hits, shades, texture evaluations: the same events whoever traces the rays) from the
+    # instrumented build on a 2-spp frame; the TIMED render uses the uninstrumented -O3 build
+    ob.select("checker")
+    ob.counters_reset()
+    ob.OracleCamera(cfg.replace(samples_per_pixel=2)).render(ob.OracleMesh(bvh), seed=args.seed, rng_kind=0, threads=cores, want_rgb=False)
+    cnt = ob.counters()
+    ob.select("fast")
+    om, oc = ob.OracleMesh(bvh), ob.OracleCamera(cfg.replace(samples_per_pixel=args.cpu_spp))
+    t1 = time.perf_counter()
+    oc.render(om, seed=args.seed, rng_kind=0, threads=cores, want_rgb=False)
+    cpu_s = time.perf_counter() - t1
+    ob.select("checker")
+    cpu_samples = cfg.width * cfg.height * args.cpu_spp
+    out["cpu_baseline"] = {
+        "value": round(cpu_samples / cpu_s / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"same scene and camera, {cfg.width}x{cfg.height} at {args.cpu_spp} spp ({cpu_samples / 1e6:.1f} Msamples, "
+                  f"{cpu_s:.1f} s): C++ restatement of the reference CPU renderer (pointer-tree BVH, virtual dispatch, "
+                  f"ChaCha12 + rejection samplers), not the Rust binary",
+        "build": "g++ " + ob.BUILD_FLAGS["fast"],
+        "rays_per_sample": round(cnt["rays"] / cnt["samples"], 3),
+        "node_tests_per_ray": round(cnt["node_tests"] / cnt["rays"], 2),
+        "prim_tests_per_ray": round((cnt["sphere_tests"] + cnt["quad_tests"]) / cnt["rays"], 2),
+    }
+    out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+
+    # algorithmic f32 operations per sample at the reference's per-event costs (FLOPS):
+    #   reference_work  every event as the reference performs it (its loose boxes make it test far more nodes)
+    #   own work        box and primitive tests as THIS RUN's kernel counted them; hits, shading and textures per sample
+    #                   as the oracle counted them (those events do not depend on who traces the ray)
+    ref_fps = sum(FLOPS[k] * cnt[k] for k in FLOPS) / cnt["samples"]
+    n_samples = samples_per_step * args.steps
+    prim_events = cnt["sphere_tests"] + cnt["quad_tests"]
+    prim_cost = (FLOPS["sphere_tests"] * cnt["sphere_tests"] + FLOPS["quad_tests"] * cnt["quad_tests"]) / max(prim_events, 1)
+    other = sum(FLOPS[k] * cnt[k] for k in FLOPS if k not in ("node_tests", "sphere_tests", "quad_tests")) / cnt["samples"]
+    own_fps = FLOPS["node_tests"] * total_box / n_samples + prim_cost * total_prim / n_samples + other
+    secs = kernel_ms * 1e-3
+    own_tf = own_fps * samples_per_step / secs / 1e12
+    ref_tf = ref_fps * samples_per_step / secs / 1e12
+    default_workload = (args.scene, args.seed, args.width, args.height, args.spp, args.depth, args.traversal, args.rr) == \
+        ("bouncing-spheres", 1, 1920, 1080, 1000, 50, "fast", 0)
+    traffic, traffic_file = measured_hbm_traffic(default_workload)
+    valu = {"bound": "valu", "kernel": "render_kernel", "achieved": round(own_tf, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(own_tf / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_file, "kernel_ms": round(kernel_ms, 3),
+            "algorithmic_flops_per_sample": round(own_fps, 1),
+            "note": "f32 operations of the kernel's own walk -- box and primitive tests counted by the kernel in this run -- plus the "
+                    "reference's hit completion, shading and texture work per sample, all at the reference's per-event costs, per "
+                    "launch / the kernel's HIP-event time",
+            "reference_work": {"flops_per_sample": round(ref_fps, 1), "achieved": round(ref_tf, 3), "frac": round(ref_tf / FP32_VECTOR_PEAK_TFLOPS, 4),
+                               "note": "the same samples priced with the tests the REFERENCE performs (its origin-including boxes make its "
+                                       "tree nearly useless): work delivered, which can exceed the peak because the kernel avoids it"}}
+    # entries beyond the LDS budget are walked from HBM / L2: node and primitive records fetched, 32 B per box, 32 B per
+    # sphere, 48 B per triangle / 68 B per quad
+    tri_like = scene.desc.n_tris > 0
+    rec_bytes = 32.0 if prim_events == 0 or cnt["quad_tests"] == 0 else (48.0 if tri_like else 68.0)
+    rec_bytes = (32.0 * cnt["sphere_tests"] + rec_bytes * cnt["quad_tests"]) / max(prim_events, 1)
+    gbs = (32.0 * total_box + rec_bytes * total_prim) / args.steps / secs / 1e9
+    hbm = {"bound": "hbm", "kernel": "render_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+           "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "traffic": None, "kernel_ms": round(kernel_ms, 3),
+           "note": "algorithmic node + primitive record bytes of the kernel's own walk (32 B per box test, 32 / 48 / 68 B per sphere / "
+                   "triangle / quad test) per launch / kernel time"}
+    if entries_in_lds:
+        out["roofline"] = valu
+    else:
+        out["roofline"] = hbm
+        out["roofline_valu"] = valu
+
+
+def in_library(args):
+    """--in-library: the multi-GPU path behind the C ABI.  One process; rtx_render_multi replicates the scene onto
+    --gpus devices, renders every share on its own stream and gathers on device 0."""
+    import numpy as np
+
+    render = importlib.import_module("ray-tracer_amd.render")
+    scenes = importlib.import_module("ray-tracer_amd.scenes")
+    world_args = {"n_lat": args.mesh_nlat} if args.mesh_nlat else None
+    cfg, bvh = scenes.make(args.scene, seed=args.seed, world_args=world_args, width=args.width, height=args.height,
+                           samples_per_pixel=args.spp, max_depth=args.depth)
+    scene, cam = render.Scene(bvh), render.Camera(cfg)
+    trav = render.TRAVERSAL_STRICT if args.traversal == "strict" else render.TRAVERSAL_FAST
+    split = render.SPLIT_TILES if args.split == "tile" else render.SPLIT_SAMPLES
+    devices = [0] * args.gpus if args.one_device else list(range(args.gpus))
+    kernel_ms, rays, box, prim = [], 0.0, 0.0, 0.0
+    rgb = None
+    for _ in range(args.warmup):
+        cam.render(scene, seed=args.seed, traversal=trav, rr_start_depth=args.rr, split=split, devices=devices)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rgb, st = cam.render(scene, seed=args.seed, traversal=trav, rr_start_depth=args.rr, split=split, devices=devices, want_stats=True)
+        kernel_ms.append(st.kernel_ms)
+        rays, box, prim = rays + st.rays, box + st.box_tests, prim + st.prim_tests
+    elapsed = time.perf_counter() - t0  # every call blocks until the frame is on the host
+    out = result_line(args, cfg, scene.n_prims, args.gpus, elapsed, rays, box, prim, float(np.mean(kernel_ms)),
+                      f"{args.split}-split x{args.gpus}, one process: rtx_render_multi, peer copies to device 0"
+                      + (" (all shares on GPU 0: rehearsal)" if args.one_device else ""))
+    if args.save:
+        from PIL import Image
+
+        Image.fromarray(rgb).save(args.save)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -197,7 +197,11 @@ typedef struct rtx_hit {
 
 enum {
     RTX_TRAVERSAL_FAST = 0,  /* library-built SAH BVH over tight boxes, closest hit with the reference's tie-break */
-    RTX_TRAVERSAL_STRICT = 1 /* walks bvh_nodes exactly as Bvh::hit does (mesh.rs:608-620), same boxes, same order */
+    RTX_TRAVERSAL_STRICT = 1, /* walks bvh_nodes exactly as Bvh::hit does (mesh.rs:608-620), same boxes, same order */
+    RTX_TRAVERSAL_FAST_FUSED = 2 /* rtx_trace only: the fast data walked with the box test the render kernels use
+                                    (one fused multiply-add per plane, hardware reciprocal).  Same hits as FAST for
+                                    ray origins inside the scene's coordinate range or, after a render, within the
+                                    reach of that render's camera: the boxes are padded for exactly that. */
 };
 
 typedef struct rtx_trace_opts {
@@ -206,15 +210,24 @@ typedef struct rtx_trace_opts {
     uint64_t seed;      /* feeds ConstantMedium's free-flight draw (mesh.rs:659) */
 } rtx_trace_opts_t;
 
+enum {
+    RTX_SPLIT_SAMPLES = 0, /* every device renders a contiguous range of the sample indices of every pixel */
+    RTX_SPLIT_TILES = 1    /* every device renders all samples of its interleaved share of the 8x8 pixel tiles */
+};
+
 typedef struct rtx_render_opts {
     uint64_t seed;
-    uint32_t sample_begin, sample_end; /* sample index range to render; 0,0 = all of 0..samples_per_pixel */
+    uint32_t sample_begin, sample_end; /* sample index range to render.  rtx_render / rtx_render_multi read 0,0 as
+                                          "all of 0..samples_per_pixel"; rtx_render_accumulate renders exactly the
+                                          range it is given (begin == end: nothing). */
     uint32_t traversal;                /* RTX_TRAVERSAL_* */
     uint32_t rr_start_depth;           /* Russian roulette from this bounce on; 0 = off (the reference has none) */
     uint32_t tile_rank, tile_world;    /* tile split: render only the 8x8 pixel tiles t with t % tile_world == tile_rank
                                           (row-major tile index); tile_world 0 or 1 = all tiles.  Other pixels of
                                           accum_dev are left untouched, so per-rank buffers add up to the frame. */
-    uint32_t reserved[2];
+    uint32_t n_gpus;                   /* rtx_render only: 0 or 1 = the scene's device; N > 1 = devices 0..N-1, driven
+                                          from this one call (see rtx_render_multi) */
+    uint32_t split;                    /* rtx_render with n_gpus > 1: RTX_SPLIT_* */
 } rtx_render_opts_t;
 
 typedef struct rtx_stats {
@@ -223,7 +236,9 @@ typedef struct rtx_stats {
     double kernel_ms;     /* device time of the path-tracing kernel(s), HIP events on the launch stream */
     double total_ms;      /* wall time of the call */
     uint32_t n_launches;  /* launches of the dominant kernel */
-    uint32_t pad;
+    uint32_t flags;       /* bit 0: the traversal entries were resident in LDS (small scene); else walked from HBM / L2 */
+    uint64_t box_tests;   /* Aabb::hit evaluations the kernel performed (lanes x box steps), counted in the kernel */
+    uint64_t prim_tests;  /* Sphere / Quad / triangle / bracket entries the kernel evaluated */
 } rtx_stats_t;
 
 typedef struct rtx_scene rtx_scene_t; /* device-resident scene */
@@ -248,9 +263,26 @@ int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t
 
 /* Camera::render (camera.rs:98-107): renders the whole frame and returns the RgbImage bytes.
  * rgb8_out: W*H*3 bytes, caller owned.  accum_out (nullable): 3*W*H f32, the per-pixel SUM of radiance
- * samples before the 1/spp scale (camera.rs:112-119).  stats nullable.  Host buffers; blocks. */
-int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
+ * samples before the 1/spp scale (camera.rs:112-119).  stats nullable.  Host buffers; blocks.
+ * opts->n_gpus > 1 renders on devices 0 .. n_gpus-1 (rtx_render_multi with devices == NULL). */
+int rtx_render(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
                uint8_t* rgb8_out, float* accum_out, rtx_stats_t* stats);
+
+/* Camera::render on several GPUs from ONE blocking call of one host thread -- the reference's render is a single
+ * blocking call (camera.rs:98, called at main.rs:579), so the library drives the devices itself: the scene's device
+ * data is replicated onto every listed device (device-to-device copies, kept with the scene for later calls), every
+ * device renders its share on its own stream -- split RTX_SPLIT_SAMPLES: the sample indices
+ * [k*spp/N, (k+1)*spp/N) of every pixel; RTX_SPLIT_TILES: all samples of the 8x8 tiles t % N == k -- and pushes its
+ * result into a staging slot on the first listed device over the GPU fabric (hipMemcpyPeerAsync): the fp32 sums,
+ * or, for a tile split without accum_out, only its resolved RGB8 bytes.  The first device adds the slots in device
+ * order and resolves.  Because the random stream is a function of (seed, pixel, sample index), the frame equals the
+ * single-device frame up to the order of fp32 additions (tile split: bit for bit).
+ * devices: n_devices HIP device ordinals, or NULL for 0 .. n_devices-1; an ordinal may repeat (several shares on
+ * one GPU: a rehearsal of the multi-GPU path on a single-GPU machine).  stats (nullable): samples, rays and test
+ * counts are summed over the devices, kernel_ms is the longest device's. */
+int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
+                     const int* devices, uint32_t n_devices, uint32_t split, uint8_t* rgb8_out, float* accum_out,
+                     rtx_stats_t* stats);
 
 /* Camera::render_pixel's sample loop (camera.rs:109-122) for the samples [sample_begin, sample_end) of every
  * pixel: ADDS their radiance sum into accum_dev (3*W*H f32, device memory, caller zeroes it).  This is the
@@ -259,7 +291,7 @@ int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_r
  * With RTX_TRAVERSAL_FAST the first call, and any call whose camera centre differs from the previous one's, first
  * waits for the device and re-orders the scene's fast traversal data for that viewpoint (nearer subtrees are
  * visited first; hits are unchanged).  Calls on one scene must therefore not overlap. */
-int rtx_render_accumulate(const rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
+int rtx_render_accumulate(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
                           float* accum_dev, void* stream, rtx_stats_t* stats);
 
 /* camera.rs:101, :119: rgb8 = round(clamp(srgb_oetf(accum * scale), 0, 1) * 255).  Device buffers. */

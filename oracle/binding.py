@@ -18,6 +18,11 @@ scene_mod = importlib.import_module("ray-tracer_amd.scene")
 
 F = np.float32
 _lib = None
+_libs = {}
+_which = "checker"
+_FILES = {"checker": "librt_oracle.so",      # -O2, work counters: what the tests compare against
+          "fast": "librt_oracle_fast.so"}    # -O3 -march=x86-64-v3, no counters: what bench.py times as the CPU baseline
+BUILD_FLAGS = {"checker": "-O2 -ffp-contract=off", "fast": "-O3 -march=x86-64-v3 -ffp-contract=off, work counters compiled out"}
 
 COUNTER_NAMES = [
     "node_tests", "sphere_tests", "sphere_hits", "quad_tests", "quad_hits", "rays", "samples", "misses",
@@ -30,11 +35,20 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def select(which):
+    """Objects created from now on live in the named build of the oracle ("checker" or "fast")."""
+    global _lib, _which
+    if which not in _FILES:
+        raise ValueError(which)
+    _which = which
+    _lib = _libs.get(which)
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(_HERE, "librt_oracle.so")
+    path = os.path.join(_HERE, _FILES[_which])
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)
@@ -66,6 +80,7 @@ def lib():
     L.orc_counters_size.restype = C.c_size_t
     L.orc_counters_get.argtypes = [C.POINTER(C.c_uint64)]
     _lib = L
+    _libs[_which] = L
     return L
 
 

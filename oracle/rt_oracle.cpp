@@ -90,10 +90,10 @@ static inline uint32_t as_u32(float v) {
 //                      kernels use, so that a GPU image can be compared sample by sample.
 // ----------------------------------------------------------------------------------------------
 struct ChaCha12 {
-    uint32_t key[8];
-    uint64_t counter;
+    uint32_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t counter = 0;
     uint32_t buf[16];
-    int idx;
+    int idx = 16;
     void seed(uint64_t s0, uint64_t s1) {
         // splitmix64 expansion of the two seed words into a 256-bit key
         uint64_t z = s0 * 0x9E3779B97F4A7C15ull + s1;
@@ -150,13 +150,15 @@ struct Rng {
         kind = 0;
         cc.seed(seed, stream);
     }
-    // identical to rng_init() of the HIP kernels
+    // identical to seed_word() + rng_init() of the HIP library: two keys hashed from both halves of the seed, then
+    // separate hash chains over (key, pixel, sample) for the state and for the increment
     void seed_mirror(uint64_t seed, uint32_t pixel, uint32_t sample) {
         kind = 1;
-        uint32_t h = pcg_hash((uint32_t)seed ^ pixel);
-        h = pcg_hash(h + sample * 0x9E3779B9u);
-        pcg_state = h;
-        pcg_inc = (pcg_hash(h ^ (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu) << 1) | 1u;
+        const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+        const uint32_t k0 = pcg_hash(lo ^ pcg_hash(hi));
+        const uint32_t k1 = pcg_hash((hi + 0x85EBCA6Bu) ^ pcg_hash(lo + 0x9E3779B9u));
+        pcg_state = pcg_hash(pcg_hash(k0 + pixel) + sample * 0x9E3779B9u);
+        pcg_inc = (pcg_hash(pcg_hash(k1 ^ pixel) + sample * 0x85EBCA6Bu) << 1) | 1u;
     }
     inline uint32_t next_u32() {
         if (kind == 0) return cc.next();
@@ -280,6 +282,12 @@ struct Counters {
     }
 };
 static thread_local Counters tl_cnt;
+// -DORC_NO_COUNTERS compiles the tallies out: the build that is TIMED as the CPU baseline carries no instrumentation.
+#ifdef ORC_NO_COUNTERS
+#define ORC_COUNT(field) ((void)0)
+#else
+#define ORC_COUNT(field) (tl_cnt.field++)
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // texture.rs
@@ -292,7 +300,7 @@ struct SolidTexture : Texture {  // texture.rs:14-44
     Vec3 albedo;
     explicit SolidTexture(Vec3 a) : albedo(a) {}
     Vec3 value(float, float, Vec3) const override {
-        tl_cnt.tex_solid++;
+        ORC_COUNT(tex_solid);
         return albedo;
     }
 };
@@ -300,7 +308,7 @@ struct CheckerTexture : Texture {  // texture.rs:46-81
     float scale;
     std::shared_ptr<Texture> even, odd;
     Vec3 value(float u, float v, Vec3 point) const override {  // texture.rs:63-74
-        tl_cnt.tex_checker++;
+        ORC_COUNT(tex_checker);
         int32_t x = as_i32(std::floor(point.x * scale));
         int32_t y = as_i32(std::floor(point.y * scale));
         int32_t z = as_i32(std::floor(point.z * scale));
@@ -313,7 +321,7 @@ struct ImageTexture : Texture {  // texture.rs:83-115; raster is the decoded RGB
     std::vector<uint8_t> rgb;
     uint32_t width = 0, height = 0;
     Vec3 value(float uu, float vv, Vec3) const override {  // texture.rs:100-114
-        tl_cnt.tex_image++;
+        ORC_COUNT(tex_image);
         float u = Interval(0.0f, 1.0f).clamp(uu);
         float v = 1.0f - Interval(0.0f, 1.0f).clamp(vv);
         uint32_t i = as_u32(u * ((float)width - 1.0f));
@@ -372,7 +380,7 @@ struct NoiseTexture : Texture {  // texture.rs:117-138
     Perlin perlin;
     float scale;
     Vec3 value(float, float, Vec3 point) const override {  // texture.rs:132-137
-        tl_cnt.tex_noise++;
+        ORC_COUNT(tex_noise);
         float s = 1.0f + std::sin(scale * point.z + 10.0f * perlin.turb(point, 7));
         // Vec3::ONE * 0.5 * (...)  evaluates (ONE*0.5) then * s
         Vec3 color = Vec3(1.0f, 1.0f, 1.0f) * 0.5f * s;
@@ -439,7 +447,7 @@ static inline Vec3 refract(Vec3 uv, Vec3 n, float etai_over_etat) {             
 struct Lambertian : Material {  // material.rs:53-96
     std::shared_ptr<Texture> texture;
     Scatter scatter(const Ray& ray, const Hit& hit) const override {  // material.rs:71-77, 87-95
-        tl_cnt.shade_lambert++;
+        ORC_COUNT(shade_lambert);
         Vec3 dir = hit.normal + random_unit_vec(*tl_rng);
         Vec3 scatter_dir = near_zero(dir) ? hit.normal : dir;
         Scatter s;
@@ -453,7 +461,7 @@ struct Metal : Material {  // material.rs:98-135
     std::shared_ptr<Texture> texture;
     float roughness = 0;
     Scatter scatter(const Ray& ray, const Hit& hit) const override {  // material.rs:105-118
-        tl_cnt.shade_metal++;
+        ORC_COUNT(shade_metal);
         Vec3 reflected = reflect(ray.direction, hit.normal) + (roughness * random_unit_vec(*tl_rng));
         Scatter s;
         s.scattered = Ray(hit.point, reflected, ray.time);
@@ -467,7 +475,7 @@ struct Metal : Material {  // material.rs:98-135
 struct Dielectric : Material {  // material.rs:137-179
     float refraction_index = 1.5f;
     Scatter scatter(const Ray& r_in, const Hit& hit) const override {  // material.rs:150-172
-        tl_cnt.shade_dielectric++;
+        ORC_COUNT(shade_dielectric);
         float ri = hit.front_face ? 1.0f / refraction_index : refraction_index;
         Vec3 unit_dir = normalize(r_in.direction);
         float cos_theta = -rmin(dot(unit_dir, hit.normal), 1.0f);
@@ -497,7 +505,7 @@ struct Dielectric : Material {  // material.rs:137-179
 struct DiffuseLight : Material {  // material.rs:181-212
     std::shared_ptr<Texture> texture;
     Scatter scatter(const Ray&, const Hit&) const override {
-        tl_cnt.shade_light++;
+        ORC_COUNT(shade_light);
         return Scatter();
     }
     Vec3 emitted(float u, float v, Vec3 p) const override { return texture->value(u, v, p); }
@@ -505,7 +513,7 @@ struct DiffuseLight : Material {  // material.rs:181-212
 struct Isotropic : Material {  // material.rs:214-246
     std::shared_ptr<Texture> texture;
     Scatter scatter(const Ray& ray, const Hit& hit) const override {  // material.rs:232-239
-        tl_cnt.shade_iso++;
+        ORC_COUNT(shade_iso);
         Scatter s;
         s.some = true;
         s.scattered = Ray(hit.point, random_unit_vec(*tl_rng), ray.time);  // field order: scattered first
@@ -546,7 +554,7 @@ struct Aabb {  // mesh.rs:434-552
         return b;
     }
     bool hit(const Ray& ray, const Interval& ray_t_in) const {  // mesh.rs:512-538
-        tl_cnt.node_tests++;
+        ORC_COUNT(node_tests);
         Interval ray_t = ray_t_in;
         for (int n = 0; n < 3; n++) {
             const Interval& iv = (*this)[n];
@@ -640,7 +648,7 @@ struct Sphere : Mesh {  // mesh.rs:103-188
         v = theta / PI;
     }
     Hit hit(const Ray& ray, const Interval& ray_t) const override {  // mesh.rs:113-139
-        tl_cnt.sphere_tests++;
+        ORC_COUNT(sphere_tests);
         Vec3 c = center(ray.time);
         Vec3 oc = c - ray.origin;
         float a = length_squared(ray.direction);
@@ -654,7 +662,7 @@ struct Sphere : Mesh {  // mesh.rs:103-188
             root = (h + sqrtd) / a;
             if (!ray_t.contains(root)) return Hit();
         }
-        tl_cnt.sphere_hits++;
+        ORC_COUNT(sphere_hits);
         Vec3 point = ray.get_point(root);
         Vec3 normal = (point - c) / radius;
         float u, v;
@@ -689,7 +697,7 @@ struct Quad : Mesh {  // mesh.rs:190-257
         return q;
     }
     Hit hit(const Ray& ray, const Interval& ray_t) const override {  // mesh.rs:202-221
-        tl_cnt.quad_tests++;
+        ORC_COUNT(quad_tests);
         float denom = dot(normal, ray.direction);
         if (std::fabs(denom) < 1e-8f) return Hit();
         float t = (d - dot(normal, ray.origin)) / denom;
@@ -700,7 +708,7 @@ struct Quad : Mesh {  // mesh.rs:190-257
         float beta = dot(w, cross(u, planar));
         Interval unit(0.0f, 1.0f);  // mesh.rs:248-256
         if (!(unit.contains(alpha) && unit.contains(beta))) return Hit();
-        tl_cnt.quad_hits++;
+        ORC_COUNT(quad_hits);
         return hit_new(ray, t, normal, material.get(), alpha, beta, prim_id);
     }
     const Aabb& bounding_box() const override { return bbox; }
@@ -731,7 +739,7 @@ struct Triangle : Mesh {
         return t;
     }
     Hit hit(const Ray& ray, const Interval& ray_t) const override {
-        tl_cnt.quad_tests++;
+        ORC_COUNT(quad_tests);
         float denom = dot(normal, ray.direction);
         if (std::fabs(denom) < 1e-8f) return Hit();
         float t = (d - dot(normal, ray.origin)) / denom;
@@ -741,7 +749,7 @@ struct Triangle : Mesh {
         float alpha = dot(w, cross(planar, v));
         float beta = dot(w, cross(u, planar));
         if (!(alpha >= 0.0f && beta >= 0.0f && alpha + beta <= 1.0f)) return Hit();
-        tl_cnt.quad_hits++;
+        ORC_COUNT(quad_hits);
         return hit_new(ray, t, normal, material.get(), alpha, beta, prim_id);
     }
     const Aabb& bounding_box() const override { return bbox; }
@@ -885,7 +893,7 @@ struct ConstantMedium : Mesh {  // mesh.rs:627-696
     float density;
     uint32_t prim_id = 0;
     Hit hit(const Ray& ray, const Interval& ray_t) const override {  // mesh.rs:634-675
-        tl_cnt.medium_tests++;
+        ORC_COUNT(medium_tests);
         Hit hit1 = boundary->hit(ray, UNIVERSE);
         if (!hit1.valid) return Hit();
         Hit hit2 = boundary->hit(ray, Interval(hit1.distance + 0.0001f, INF));
@@ -987,10 +995,10 @@ struct Camera {  // camera.rs:45-169
     }
     Vec3 ray_color(const Ray& ray, const Mesh& world, uint32_t depth) const {  // camera.rs:124-145
         if (depth <= 0) {
-            tl_cnt.depth_exhausted++;
+            ORC_COUNT(depth_exhausted);
             return Vec3(0, 0, 0);
         }
-        tl_cnt.rays++;
+        ORC_COUNT(rays);
         Hit hit = world.hit(ray, Interval(0.001f, INF));
         if (hit.valid) {
             Vec3 color_from_emission = hit.material->emitted(hit.u, hit.v, hit.point);
@@ -1001,7 +1009,7 @@ struct Camera {  // camera.rs:45-169
             }
             return color_from_emission;
         }
-        tl_cnt.misses++;
+        ORC_COUNT(misses);
         return config.background;
     }
 };
@@ -1301,7 +1309,7 @@ void orc_render(orc_camera* c, orc_mesh* m, uint64_t seed, int rng_kind, uint32_
                 for (uint32_t s = sample_begin; s < sample_end; s++) {
                     if (rng_kind == 1) rng.seed_mirror(seed, (uint32_t)p, s);
                     Ray ray = cam.get_ray(rng, x, y);
-                    tl_cnt.samples++;
+                    ORC_COUNT(samples);
                     color = color + cam.ray_color(ray, world, cam.config.max_depth);
                 }
                 if (accum_out) {

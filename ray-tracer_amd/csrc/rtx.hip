@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "accel.hpp"
@@ -41,36 +42,53 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 // ================================================================================================ scene
-struct rtx_scene {
+constexpr size_t COUNTER_BYTES = 256;  // [0] item counter (u32); u64 words from byte 8: rays, box tests, primitive tests, then diagnostics
+
+// The scene's device data on one GPU, with the render scratch that goes with it.
+struct DeviceCopy {
     int device = 0;
+    int n_cus = 0;
     DevScene dev{};
-    std::vector<void*> allocs;
-    uint32_t n_ents[2] = {0, 0};
-    uint32_t n_boxes[2] = {0, 0};
-    // render scratch (per scene, grown on demand)
+    std::vector<std::pair<void*, size_t>> allocs;  // everything `dev` points into, in upload order
+    // render scratch (grown on demand)
     float* partial = nullptr;
     size_t partial_bytes = 0;
-    uint32_t* counters = nullptr;  // [0] item counter, [2..3] ray counter (u64)
+    uint32_t* counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int n_cus = 0;
-    float coord_range = 0.0f;    // largest |coordinate| the fast boxes were padded for
-    uint32_t n_perlins = 0;
-    bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
-    bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
-    // the fast array in entry-index form and the viewpoint its device copy is currently ordered for
-    std::vector<uint4> mat_recs;  // 2 per material: the shading record a hit entry gets (see DevScene::shade)
-    rtx_accel::Threaded fast_indexed;
+    // the viewpoint this copy's fast array is currently ordered for
     float view[3] = {0, 0, 0};
     float view_grow = 0.0f;
     bool view_valid = false;
+    // rtx_render_multi only: this share's stream, sums and bytes; staging slots on the gathering device
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float* accum = nullptr;
+    uint8_t* rgb = nullptr;
+    void* staging = nullptr;
+    size_t accum_bytes = 0, rgb_bytes = 0, staging_bytes = 0;
+};
+
+struct rtx_scene {
+    DeviceCopy primary;
+    std::vector<DeviceCopy*> replicas;  // rtx_render_multi: share k > 0 (or share 0 on another device than the primary's)
+    uint32_t n_ents[2] = {0, 0};
+    uint32_t n_boxes[2] = {0, 0};
+    float coord_range = 0.0f;    // largest |coordinate| the fast boxes were padded for
+    uint32_t n_perlins = 0;
+    uint32_t n_images = 0;
+    bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
+    bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
+    // the fast array in entry-index form: re-ordered for a viewpoint when a render asks for it
+    std::vector<uint4> mat_recs;  // 2 per material: the shading record a hit entry gets (see DevScene::shade)
+    rtx_accel::Threaded fast_indexed;
 };
 
 template <class T>
-static int upload(rtx_scene* s, const std::vector<T>& host, const T** dev_out) {
+static int upload(DeviceCopy* c, const std::vector<T>& host, const T** dev_out) {
     void* p = nullptr;
     size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
     HIP_TRY(hipMalloc(&p, bytes));
-    s->allocs.push_back(p);
+    c->allocs.emplace_back(p, bytes);
     if (!host.empty()) HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     *dev_out = reinterpret_cast<const T*>(p);
     return RTX_OK;
@@ -148,16 +166,32 @@ static int validate(const rtx_scene_desc_t* d) {
     return RTX_OK;
 }
 
+// Frees what a copy holds on its device (the current device is changed and not restored).
+static void release_copy(DeviceCopy* c) {
+    hipSetDevice(c->device);
+    for (auto& a : c->allocs) hipFree(a.first);
+    if (c->partial) hipFree(c->partial);
+    if (c->counters) hipFree(c->counters);
+    if (c->accum) hipFree(c->accum);
+    if (c->rgb) hipFree(c->rgb);
+    if (c->staging) hipFree(c->staging);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->done) hipEventDestroy(c->done);
+    if (c->stream) hipStreamDestroy(c->stream);
+    *c = DeviceCopy();
+}
+
 extern "C" void rtx_scene_destroy(rtx_scene_t* s) {
     if (!s) return;
     int prev = 0;
     hipGetDevice(&prev);
-    hipSetDevice(s->device);
-    for (void* p : s->allocs) hipFree(p);
-    if (s->partial) hipFree(s->partial);
-    if (s->counters) hipFree(s->counters);
-    if (s->ev0) hipEventDestroy(s->ev0);
-    if (s->ev1) hipEventDestroy(s->ev1);
+    for (DeviceCopy* r : s->replicas) {
+        if (!r) continue;
+        release_copy(r);
+        delete r;
+    }
+    release_copy(&s->primary);
     hipSetDevice(prev);
     delete s;
 }
@@ -203,16 +237,17 @@ static std::vector<uint4> expand_shade(const rtx_accel::Threaded& t, const std::
 }
 
 static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
+    DeviceCopy* dc = &s->primary;
     rtx_accel::Threaded strict, fast;
     std::string err;
     int rc = rtx_accel::build(*d, strict, fast, s->fast_indexed, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
     if (strict.has_brackets) s->has_brackets = true;  // transforms / media need the bracket-aware kernel variant
 
-    HIP_TRY(hipGetDevice(&s->device));
+    HIP_TRY(hipGetDevice(&dc->device));
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-    s->n_cus = prop.multiProcessorCount;
+    HIP_TRY(hipGetDeviceProperties(&prop, dc->device));
+    dc->n_cus = prop.multiProcessorCount;
 
     // shading record per material: kind, flags, parameter, and the colour when the texture is a plain solid one
     // (the dielectric attenuates with white, material.rs:175)
@@ -243,11 +278,11 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     const rtx_accel::Threaded* th[2] = {&fast, &strict};
     for (int m = 0; m < 2; m++) {
         const rtx_accel::Ent* ep = nullptr;
-        if ((rc = upload(s, th[m]->ents, &ep)) != RTX_OK) return rc;
-        s->dev.ents[m] = reinterpret_cast<const uint4*>(ep);
-        if ((rc = upload(s, th[m]->rank, &s->dev.rank[m])) != RTX_OK) return rc;
-        if ((rc = upload(s, expand_shade(*th[m], s->mat_recs), &s->dev.shade[m])) != RTX_OK) return rc;
-        s->dev.n_ents[m] = s->n_ents[m] = (uint32_t)th[m]->ents.size();  // terminator included
+        if ((rc = upload(dc, th[m]->ents, &ep)) != RTX_OK) return rc;
+        dc->dev.ents[m] = reinterpret_cast<const uint4*>(ep);
+        if ((rc = upload(dc, th[m]->rank, &dc->dev.rank[m])) != RTX_OK) return rc;
+        if ((rc = upload(dc, expand_shade(*th[m], s->mat_recs), &dc->dev.shade[m])) != RTX_OK) return rc;
+        dc->dev.n_ents[m] = s->n_ents[m] = (uint32_t)th[m]->ents.size();  // terminator included
         s->n_boxes[m] = th[m]->n_boxes;
     }
     auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
@@ -260,8 +295,8 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         sph[2 * i + 1] = make_float4(d->sph_dx[i], d->sph_dy[i], d->sph_dz[i], bf(d->sph_material[i]));
         sph_id[i] = d->sph_prim_id[i];
     }
-    if ((rc = upload(s, sph, &s->dev.sph)) != RTX_OK) return rc;
-    if ((rc = upload(s, sph_id, &s->dev.sph_id)) != RTX_OK) return rc;
+    if ((rc = upload(dc, sph, &dc->dev.sph)) != RTX_OK) return rc;
+    if ((rc = upload(dc, sph_id, &dc->dev.sph_id)) != RTX_OK) return rc;
 
     // planar records: quads as given; triangles through the same derivation Quad::new applies to (Q, u, v)
     // (mesh.rs:233-244) with Q = v0, u = v1 - v0, v = v2 - v0.
@@ -295,9 +330,9 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         planar[5 * p + 4] = make_float4(n[0] / nn, n[1] / nn, n[2] / nn, 0.0f);
         planar_id[p] = d->tri_prim_id[i];
     }
-    if ((rc = upload(s, planar, &s->dev.planar)) != RTX_OK) return rc;
-    if ((rc = upload(s, planar_id, &s->dev.planar_id)) != RTX_OK) return rc;
-    s->dev.n_quads = d->n_quads;
+    if ((rc = upload(dc, planar, &dc->dev.planar)) != RTX_OK) return rc;
+    if ((rc = upload(dc, planar_id, &dc->dev.planar_id)) != RTX_OK) return rc;
+    dc->dev.n_quads = d->n_quads;
 
     std::vector<uint4> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; i++) {
@@ -305,7 +340,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         uint32_t flags = (m.kind != RTX_MAT_DIELECTRIC && tex_reads_uv(*d, m.texture)) ? 1u : 0u;
         mats[i] = make_uint4(m.kind, m.texture, fb(m.param), flags);
     }
-    if ((rc = upload(s, mats, &s->dev.mats)) != RTX_OK) return rc;
+    if ((rc = upload(dc, mats, &dc->dev.mats)) != RTX_OK) return rc;
 
     std::vector<uint4> texs(2 * (size_t)d->n_textures);
     for (uint32_t i = 0; i < d->n_textures; i++) {
@@ -313,7 +348,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         texs[2 * i] = make_uint4(t.kind, fb(t.scale), t.a, t.b);
         texs[2 * i + 1] = make_uint4(fb(t.rgb[0]), fb(t.rgb[1]), fb(t.rgb[2]), 0);
     }
-    if ((rc = upload(s, texs, &s->dev.texs)) != RTX_OK) return rc;
+    if ((rc = upload(dc, texs, &dc->dev.texs)) != RTX_OK) return rc;
     for (uint32_t i = 0; i < d->n_textures; i++)
         if (d->textures[i].kind == RTX_TEX_IMAGE || d->textures[i].kind == RTX_TEX_NOISE) s->has_tex = true;
 
@@ -322,10 +357,10 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         const rtx_image_t& im = d->images[i];
         std::vector<uint8_t> px(im.rgb, im.rgb + (size_t)im.width * im.height * 3);
         const uint8_t* dp = nullptr;
-        if ((rc = upload(s, px, &dp)) != RTX_OK) return rc;
+        if ((rc = upload(dc, px, &dp)) != RTX_OK) return rc;
         images[i] = DevImage{dp, im.width, im.height};
     }
-    if ((rc = upload(s, images, &s->dev.images)) != RTX_OK) return rc;
+    if ((rc = upload(dc, images, &dc->dev.images)) != RTX_OK) return rc;
 
     std::vector<float> perlin(1536 * (size_t)d->n_perlins);
     for (uint32_t i = 0; i < d->n_perlins; i++) {
@@ -336,12 +371,13 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
         std::memcpy(dst + 1024, p.perm_y, 256 * 4);
         std::memcpy(dst + 1280, p.perm_z, 256 * 4);
     }
-    if ((rc = upload(s, perlin, &s->dev.perlin)) != RTX_OK) return rc;
+    if ((rc = upload(dc, perlin, &dc->dev.perlin)) != RTX_OK) return rc;
     s->n_perlins = d->n_perlins;
 
-    HIP_TRY(hipMalloc((void**)&s->counters, 128));
-    HIP_TRY(hipEventCreate(&s->ev0));
-    HIP_TRY(hipEventCreate(&s->ev1));
+    s->n_images = d->n_images;
+    HIP_TRY(hipMalloc((void**)&dc->counters, COUNTER_BYTES));
+    HIP_TRY(hipEventCreate(&dc->ev0));
+    HIP_TRY(hipEventCreate(&dc->ev1));
     return RTX_OK;
 }
 
@@ -363,14 +399,23 @@ extern "C" int rtx_scene_create(const rtx_scene_desc_t* desc, rtx_scene_t** out)
     return RTX_OK;
 }
 
+static uint32_t seed_word(uint64_t seed, int which) {  // the two 32-bit words the kernels key their streams on (rng_init)
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    auto h = [](uint32_t v) {
+        uint32_t s = v * 747796405u + 2891336453u;
+        uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+        return (w >> 22u) ^ w;
+    };
+    return which == 0 ? h(lo ^ h(hi)) : h((hi + 0x85EBCA6Bu) ^ h(lo + 0x9E3779B9u));
+}
+
 // ================================================================================================ trace
-template <bool STRICT>
-__global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax, uint64_t seed,
-                                                    rtx_hit_t* __restrict__ hits) {
+template <bool STRICT, int SLAB>
+__global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax, uint32_t seed0,
+                                                    uint32_t seed1, rtx_hit_t* __restrict__ hits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
-    constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_ROBUST;
     const uint4* __restrict__ ents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
     const EntReader reader{ents};
@@ -380,7 +425,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
     wray.time = rays[i].time;
     Ray r = wray;
     RayConst rc = ray_const<SLAB>(r);
-    Rng rng = rng_init(seed, (uint32_t)i, 0u);  // only a ConstantMedium draws from it (mesh.rs:659)
+    Rng rng = rng_init(seed0, seed1, (uint32_t)i, 0u);  // only a ConstantMedium draws from it (mesh.rs:659)
     WalkX x;
     walkx_init(x, tmin);
     Best best;
@@ -395,7 +440,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
             bracket_step<STRICT, SLAB>(reader, ea, eb, off, r, rc, wray, best, x, tmin, rng, rank);
         } else {
             const uint32_t at = off;
-            off = walk_step<STRICT>(S, ea, eb, off, r, rc, x.tmin, best, rank);
+            off = walk_step<STRICT, SLAB>(S, ea, eb, off, r, rc, x.tmin, best, rank);
             if (best.ent == at) x.best_xf = x.cur_xf;
         }
     }
@@ -422,15 +467,18 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
 extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
                                 void* stream) {
     if (!scene || !opts || (n && (!rays_dev || !hits_dev))) return fail(RTX_ERR_INVALID, "null argument");
-    if (opts->traversal > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    if (opts->traversal > RTX_TRAVERSAL_FAST_FUSED) return fail(RTX_ERR_INVALID, "unknown traversal mode");
     if (n == 0) return RTX_OK;
     if (n > ((size_t)1 << 39)) return fail(RTX_ERR_INVALID, "too many rays for one call");
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
+    const DevScene& S = scene->primary.dev;
     if (opts->traversal == RTX_TRAVERSAL_STRICT)
-        hipLaunchKernelGGL(trace_kernel<true>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, opts->seed, hits_dev);
+        hipLaunchKernelGGL((trace_kernel<true, SLAB_STRICT>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+    else if (opts->traversal == RTX_TRAVERSAL_FAST)
+        hipLaunchKernelGGL((trace_kernel<false, SLAB_ROBUST>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     else
-        hipLaunchKernelGGL(trace_kernel<false>, grid, block, 0, st, scene->dev, rays_dev, n, opts->tmin, opts->tmax, opts->seed, hits_dev);
+        hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
 }
@@ -438,7 +486,7 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
 extern "C" int rtx_trace(const rtx_scene_t* scene, const rtx_ray_t* rays, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_out) {
     if (!scene || !opts || (n && (!rays || !hits_out))) return fail(RTX_ERR_INVALID, "null argument");
     if (n == 0) return RTX_OK;
-    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipSetDevice(scene->primary.device));
     rtx_ray_t* dr = nullptr;
     rtx_hit_t* dh = nullptr;
     HIP_TRY(hipMalloc((void**)&dr, n * sizeof(rtx_ray_t)));
@@ -467,7 +515,7 @@ extern "C" int rtx_trace(const rtx_scene_t* scene, const rtx_ray_t* rays, size_t
 struct RenderParams {
     DevScene S;
     rtx_camera_t cam;
-    uint64_t seed;
+    uint32_t seed0, seed1;  // the two stream keys derived from the 64-bit seed (seed_word)
     uint32_t sample_begin, sample_end;
     uint32_t batch;       // samples per item
     uint32_t n_batches;
@@ -481,7 +529,7 @@ struct RenderParams {
     uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
     uint32_t overlap;     // 1: free lanes start on the wave's next item while the current one drains
     uint32_t* item_counter;
-    unsigned long long* ray_counter;
+    unsigned long long* ray_counter;  // [0] rays, [1] box tests, [2] primitive tests (then diagnostics)
     float* partial;       // [n_batches][H][W][3]
 };
 
@@ -528,6 +576,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     const rtx_camera_t& C = P.cam;
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     uint32_t rays_traced = 0;  // per lane; summed in 64 bits at the end
+    uint32_t wave_box = 0, wave_prim = 0;  // wave-uniform: lanes x steps of the box / primitive stage = tests performed
 #ifdef RTX_STAGE_COUNTERS
     unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
     unsigned long long tc[4] = {0, 0, 0, 0};              // wave clocks inside the box / primitive / service stage, and in total
@@ -649,6 +698,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         dst[1] = acc[a_sel * ACC_FLOATS + lane * 3 + 1];
                         dst[2] = acc[a_sel * ACC_FLOATS + lane * 3 + 2];
                     }
+                    if ((wave_box | wave_prim) >= 0x40000000u) {  // keep the 32-bit tallies from wrapping on very long launches
+                        if (lane == 0) {
+                            atomicAdd(P.ray_counter + 1, (unsigned long long)wave_box);
+                            atomicAdd(P.ray_counter + 2, (unsigned long long)wave_prim);
+                        }
+                        wave_box = 0;
+                        wave_prim = 0;
+                    }
                     if (B.pool_total == 0u && more) RTX_CLAIM(B, a_sel ^ 1u);
                     if (B.pool_total == 0u) break;  // nothing left anywhere
                     A = B;
@@ -677,7 +734,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 RTX_TIC();
                 uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
                 if (st == ENT_BOX) RTX_LOAD_ENTRY(off, ea, eb);
+                nb = n_box;
                 do {
+                    wave_box += nb;
 #ifdef RTX_STAGE_COUNTERS
                     sc[0]++;
                     sc[1] += __popcll(__ballot(st == ENT_BOX));
@@ -695,9 +754,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive; repeated
                 //      while primitives stay the bulk of the work (lists, leaves and instances put them in a row)
                 const uint32_t n_fixed = n_box + n_prim + n_serv;
-                uint32_t np;
+                uint32_t np = n_prim;
                 RTX_TIC();
                 do {
+                    wave_prim += np;
 #ifdef RTX_STAGE_COUNTERS
                     sc[2]++;
                     sc[3] += __popcll(__ballot(st - 1u < ENT_END - 1u));
@@ -821,7 +881,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                     if (st == ST_IDLE && my < g_total && x < C.width && y < C.height) {
                         slot = my_slot | (g_sel << 6);
                         const uint32_t sample = g_s0 + (my >> 6);
-                        rng = rng_init(P.seed, y * C.width + x, sample);
+                        rng = rng_init(P.seed0, P.seed1, y * C.width + x, sample);
                         const float ox = rng_f32(rng) - 0.5f;
                         const float oy = rng_f32(rng) - 0.5f;
                         const float fx = (float)x + ox, fy = (float)y + oy;
@@ -862,12 +922,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     // one ray-count update per wave
     unsigned long long wave_rays = rays_traced;
     for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
-    if (lane == 0 && wave_rays) atomicAdd(P.ray_counter, wave_rays);
+    if (lane == 0) {
+        if (wave_rays) atomicAdd(P.ray_counter, wave_rays);
+        if (wave_box) atomicAdd(P.ray_counter + 1, (unsigned long long)wave_box);
+        if (wave_prim) atomicAdd(P.ray_counter + 2, (unsigned long long)wave_prim);
+    }
 #ifdef RTX_STAGE_COUNTERS
     tc[3] = __builtin_readcyclecounter() - t_begin;
     if (lane == 0) {
-        for (int i = 0; i < 8; i++) atomicAdd(P.ray_counter + 1 + i, sc[i]);
-        for (int i = 0; i < 4; i++) atomicAdd(P.ray_counter + 9 + i, tc[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(P.ray_counter + 6 + i, sc[i]);
+        for (int i = 0; i < 4; i++) atomicAdd(P.ray_counter + 14 + i, tc[i]);
     }
 #endif
 #undef RTX_TIC
@@ -897,95 +961,153 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float* __restrict__ 
 static int check_camera(const rtx_camera_t* c) {
     if (!c) return fail(RTX_ERR_INVALID, "null camera");
     if (c->width == 0 || c->height == 0) return fail(RTX_ERR_INVALID, "zero image size");
+    // a tile origin is kept as x | y << 16
+    if (c->width > 65535u || c->height > 65535u) return fail(RTX_ERR_INVALID, "image wider or taller than 65535 pixels");
     if ((uint64_t)c->width * c->height > (1ull << 30)) return fail(RTX_ERR_INVALID, "image too large");
     if (c->samples_per_pixel == 0) return fail(RTX_ERR_INVALID, "samples_per_pixel is zero");
     return RTX_OK;
 }
 
-static uint32_t env_u32(const char* name, uint32_t dflt) {
-    const char* v = std::getenv(name);
-    return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
+// Tuning knobs, read from the environment once per process.
+struct Knobs {
+    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, overlap, lds_ents_max, perlin_lds, waves_per_block,
+        blocks_per_cu, debug;
+};
+static const Knobs& knobs() {
+    static const Knobs k = [] {
+        auto u = [](const char* name, uint32_t dflt) {
+            const char* v = std::getenv(name);
+            return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
+        };
+        Knobs x;
+        x.view_order = u("RTX_VIEW_ORDER", 1);
+        x.items_per_wave = u("RTX_ITEMS_PER_WAVE", 0);
+        x.max_batches = u("RTX_MAX_BATCHES", 64);
+        x.sched_k = std::max(1u, u("RTX_SCHED_K", 4));
+        x.w_prim = std::max(1u, u("RTX_W_PRIM", 10));
+        x.w_serv = std::max(1u, u("RTX_W_SERV", 3));
+        x.sched_kp = u("RTX_SCHED_KP", 32);
+        x.overlap = u("RTX_OVERLAP", 1);
+        x.lds_ents_max = u("RTX_LDS_ENTS_MAX", 72 * 1024);
+        x.perlin_lds = u("RTX_PERLIN_LDS", 1);
+        x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
+        x.blocks_per_cu = u("RTX_BLOCKS_PER_CU", 0);
+        x.debug = u("RTX_DEBUG", 0);
+        return x;
+    }();
+    return k;
+}
+
+// What a camera needs from the fast array: the viewpoint it should be ordered for and how far its boxes must be grown.
+// `reach` is the largest |coordinate| a camera ray can start from; beyond the range the boxes were padded for, they are
+// enlarged by the rounding error of the fused box test at that distance (~1.2e-7 * |origin| per plane, taken 4x).
+struct ViewNeed {
+    bool strict_only;  // no finite reach: only the strict walk is safe
+    float grow;
+};
+static ViewNeed view_need(const rtx_scene* scene, const rtx_camera_t* cam) {
+    float cmax = std::fmax(std::fabs(cam->center[0]), std::fmax(std::fabs(cam->center[1]), std::fabs(cam->center[2])));
+    float dmax = 0.0f;
+    for (int k = 0; k < 3; k++) dmax = std::fmax(dmax, std::fmax(std::fabs(cam->defocus_disk_u[k]), std::fabs(cam->defocus_disk_v[k])));
+    const float reach = cmax + 2.0f * dmax;
+    ViewNeed n;
+    n.strict_only = !std::isfinite(reach) || reach > 1e12f;
+    n.grow = (!n.strict_only && reach > scene->coord_range) ? 4.5e-7f * reach : 0.0f;
+    return n;
 }
 
 // Re-orders the fast array for rays leaving `center` (children nearer to it are visited first) and replaces the device
-// copy.  Only the visiting order changes: every trace returns the same hit as before.  `reach` is the largest
-// |coordinate| a camera ray can start from; beyond the range the boxes were padded for, they are enlarged by the
-// rounding error of the fused box test at that distance (~1.2e-7 * |origin| per plane, taken 4x).
-static int order_fast_for_view(rtx_scene* scene, const float center[3], float reach) {
-    const float grow = reach > scene->coord_range ? 4.5e-7f * reach : 0.0f;
-    if (scene->view_valid && std::memcmp(scene->view, center, sizeof(scene->view)) == 0 && grow == scene->view_grow) return RTX_OK;
+// copy.  Only the visiting order changes: every trace returns the same hit as before.
+static int order_fast_for_view(rtx_scene* scene, DeviceCopy* c, const float center[3], float grow) {
+    if (c->view_valid && std::memcmp(c->view, center, sizeof(c->view)) == 0 && grow == c->view_grow) return RTX_OK;
     rtx_accel::Threaded ordered;
     rtx_accel::Reorder(scene->fast_indexed, ordered).run(center, grow);
     rtx_accel::finalize(ordered);
     if (ordered.ents.size() != scene->n_ents[RTX_TRAVERSAL_FAST]) return fail(RTX_ERR_DEVICE, "internal: re-ordered array changed size");
     HIP_TRY(hipDeviceSynchronize());  // no walk may be in flight while the array is replaced
-    HIP_TRY(hipMemcpy(const_cast<uint4*>(scene->dev.ents[RTX_TRAVERSAL_FAST]), ordered.ents.data(), ordered.ents.size() * sizeof(rtx_accel::Ent), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(const_cast<uint32_t*>(scene->dev.rank[RTX_TRAVERSAL_FAST]), ordered.rank.data(), ordered.rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<uint4*>(c->dev.ents[RTX_TRAVERSAL_FAST]), ordered.ents.data(), ordered.ents.size() * sizeof(rtx_accel::Ent), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<uint32_t*>(c->dev.rank[RTX_TRAVERSAL_FAST]), ordered.rank.data(), ordered.rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     const std::vector<uint4> shade = expand_shade(ordered, scene->mat_recs);
-    HIP_TRY(hipMemcpy(const_cast<uint4*>(scene->dev.shade[RTX_TRAVERSAL_FAST]), shade.data(), shade.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    std::memcpy(scene->view, center, sizeof(scene->view));
-    scene->view_grow = grow;
-    scene->view_valid = true;
+    HIP_TRY(hipMemcpy(const_cast<uint4*>(c->dev.shade[RTX_TRAVERSAL_FAST]), shade.data(), shade.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    std::memcpy(c->view, center, sizeof(c->view));
+    c->view_grow = grow;
+    c->view_valid = true;
     return RTX_OK;
 }
 
-extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camera_t* cam, const rtx_render_opts_t* opts, float* accum_dev, void* stream,
-                                     rtx_stats_t* stats) {
-    rtx_scene* scene = const_cast<rtx_scene*>(scene_c);
+// Where a render keeps its library-owned device memory.
+struct Scratch {
+    float* partial;        // per-batch partial images
+    size_t partial_bytes;  // capacity
+    uint32_t* counters;    // COUNTER_BYTES
+    bool may_grow;         // partial may be re-allocated to the size the frame wants
+};
+
+// One render_kernel launch + reduce on copy `c` (which lives on the current device).
+static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camera_t* cam, const rtx_render_opts_t* opts, float* accum_dev,
+                                hipStream_t st, rtx_stats_t* stats, Scratch* scratch, bool may_prepare) {
     if (!scene || !opts || !accum_dev) return fail(RTX_ERR_INVALID, "null argument");
     int rc = check_camera(cam);
     if (rc != RTX_OK) return rc;
     if (opts->traversal > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
-    uint32_t sb = opts->sample_begin, se = opts->sample_end;
-    if (sb == 0 && se == 0) se = cam->samples_per_pixel;
+    const uint32_t sb = opts->sample_begin, se = opts->sample_end;
     if (se < sb) return fail(RTX_ERR_INVALID, "sample_end < sample_begin");
     auto t_start = std::chrono::steady_clock::now();
-    hipStream_t st = (hipStream_t)stream;
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (se == sb) return RTX_OK;
     int cur = -1;
     HIP_TRY(hipGetDevice(&cur));
-    if (cur != scene->device) return fail(RTX_ERR_INVALID, "scene lives on another device than the current one");
+    if (cur != c->device) return fail(RTX_ERR_INVALID, "scene lives on another device than the current one");
+    const Knobs& K = knobs();
 
     uint32_t M = opts->traversal;
     if (M == RTX_TRAVERSAL_FAST) {
         // The fused box test of the fast walk needs boxes padded for the distance rays start from: the scene's own
         // coordinate range covers bounce rays, the camera's position is covered when the array is ordered for it.
-        float cmax = std::fmax(std::fabs(cam->center[0]), std::fmax(std::fabs(cam->center[1]), std::fabs(cam->center[2])));
-        float dmax = 0.0f;
-        for (int k = 0; k < 3; k++) dmax = std::fmax(dmax, std::fmax(std::fabs(cam->defocus_disk_u[k]), std::fabs(cam->defocus_disk_v[k])));
-        const float reach = cmax + 2.0f * dmax;
-        if (!std::isfinite(reach) || reach > 1e12f) {
+        const ViewNeed need = view_need(scene, cam);
+        if (need.strict_only) {
             M = RTX_TRAVERSAL_STRICT;
-        } else if (env_u32("RTX_VIEW_ORDER", 1) != 0u || reach > scene->coord_range) {
-            if ((rc = order_fast_for_view(scene, cam->center, reach)) != RTX_OK) return rc;
+        } else if (may_prepare) {
+            if (K.view_order != 0u || need.grow > 0.0f) {
+                if ((rc = order_fast_for_view(scene, c, cam->center, need.grow)) != RTX_OK) return rc;
+            }
+        } else if ((c->view_valid ? c->view_grow : 0.0f) < need.grow) {
+            return fail(RTX_ERR_UNSUPPORTED, "the scene's fast traversal data is not prepared for this camera position: render once with "
+                                             "rtx_render_accumulate from this camera centre first, or use RTX_TRAVERSAL_STRICT");
         }
     }
     RenderParams P;
     std::memset(&P, 0, sizeof(P));
-    P.S = scene->dev;
+    P.S = c->dev;
     P.cam = *cam;
-    P.seed = opts->seed;
+    P.seed0 = seed_word(opts->seed, 0);
+    P.seed1 = seed_word(opts->seed, 1);
     P.sample_begin = sb;
     P.sample_end = se;
     P.tiles_x = (cam->width + TILE - 1) / TILE;
     P.tiles_y = (cam->height + TILE - 1) / TILE;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t spp = se - sb;
+    const size_t npix3 = (size_t)cam->width * cam->height * 3;
     // The sample range is cut into batches so that the chip's waves (CUs x 32) get several items each: many items
     // balance the tail of the launch, but an item shorter than ~20 samples per pixel spends too much of its life
     // filling and draining.  Between 4 and 64 items per wave, as many as keep a batch at 20 samples or more.
-    const uint32_t waves = (uint32_t)scene->n_cus * 32u;
-    const uint32_t fixed_ipw = env_u32("RTX_ITEMS_PER_WAVE", 0);
+    const uint32_t waves = (uint32_t)c->n_cus * 32u;
     uint32_t n_batches;
-    if (fixed_ipw != 0u) {
-        n_batches = (waves * fixed_ipw + n_tiles - 1) / n_tiles;
+    if (K.items_per_wave != 0u) {
+        n_batches = (waves * K.items_per_wave + n_tiles - 1) / n_tiles;
     } else {
         const uint32_t lo = (waves * 4u + n_tiles - 1) / n_tiles, hi = (waves * 64u + n_tiles - 1) / n_tiles;
         n_batches = std::min(hi, std::max(lo, spp / 20u));
     }
     n_batches = std::min<uint32_t>(spp, std::max<uint32_t>(1u, n_batches));
-    n_batches = std::min<uint32_t>(n_batches, env_u32("RTX_MAX_BATCHES", 64));
+    n_batches = std::min<uint32_t>(n_batches, std::max(1u, K.max_batches));
+    if (!scratch->may_grow) {
+        // fixed scratch: as many batches as fit
+        const size_t fit = scratch->partial_bytes / (npix3 * sizeof(float));
+        if (fit == 0) return fail(RTX_ERR_UNSUPPORTED, "frame too large for the fixed scratch array: 12 * width * height bytes exceed RTX_STATIC_SCRATCH_BYTES");
+        n_batches = (uint32_t)std::min<size_t>(n_batches, fit);
+    }
     P.batch = (spp + n_batches - 1) / n_batches;
     P.n_batches = (spp + P.batch - 1) / P.batch;
     P.tile_world = std::max<uint32_t>(1u, opts->tile_world);
@@ -995,29 +1117,30 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     P.n_items = P.n_owned * P.n_batches;
     if (P.n_items == 0) return RTX_OK;
     P.rr_start = opts->rr_start_depth;
-    P.sched_k = std::max<uint32_t>(1u, env_u32("RTX_SCHED_K", 4));
-    P.w_prim = std::max<uint32_t>(1u, env_u32("RTX_W_PRIM", 10));
-    P.w_serv = std::max<uint32_t>(1u, env_u32("RTX_W_SERV", 3));
-    P.sched_kp = env_u32("RTX_SCHED_KP", 32);
-    P.overlap = env_u32("RTX_OVERLAP", 1);
+    P.sched_k = K.sched_k;
+    P.w_prim = K.w_prim;
+    P.w_serv = K.w_serv;
+    P.sched_kp = K.sched_kp;
+    P.overlap = K.overlap;
 
-    const size_t npix3 = (size_t)cam->width * cam->height * 3;
     const size_t need = npix3 * sizeof(float) * P.n_batches;
-    if (scene->partial_bytes < need) {
+    if (scratch->partial_bytes < need) {  // only with may_grow
         HIP_TRY(hipStreamSynchronize(st));
-        if (scene->partial) hipFree(scene->partial);
-        scene->partial = nullptr;
-        scene->partial_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&scene->partial, need));
-        scene->partial_bytes = need;
+        if (c->partial) hipFree(c->partial);
+        c->partial = nullptr;
+        c->partial_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&c->partial, need));
+        c->partial_bytes = need;
+        scratch->partial = c->partial;
+        scratch->partial_bytes = need;
     }
-    P.partial = scene->partial;
-    P.item_counter = scene->counters;
-    P.ray_counter = reinterpret_cast<unsigned long long*>(scene->counters + 2);
-    HIP_TRY(hipMemsetAsync(scene->counters, 0, 128, st));
+    P.partial = scratch->partial;
+    P.item_counter = scratch->counters;
+    P.ray_counter = reinterpret_cast<unsigned long long*>(scratch->counters + 2);
+    HIP_TRY(hipMemsetAsync(scratch->counters, 0, COUNTER_BYTES, st));
 
     const size_t ent_bytes = (size_t)scene->n_ents[M] * 32;
-    const bool in_lds = ent_bytes <= env_u32("RTX_LDS_ENTS_MAX", 72 * 1024);
+    const bool in_lds = ent_bytes <= K.lds_ents_max;
     // one instantiation per (traversal, entries in LDS, brackets, uv / noise textures): features a scene does not use
     // cost registers, and registers cost resident waves
     static void (*const kernels[16])(RenderParams) = {
@@ -1030,7 +1153,7 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
     void (*kern)(RenderParams) = kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
     // noise textures read their tables 336 times per value: table set 0 goes to LDS (6 KB per block)
-    const size_t perlin_lds = scene->has_tex && scene->n_perlins != 0 && env_u32("RTX_PERLIN_LDS", 1) != 0u ? 1536 * sizeof(float) : 0;
+    const size_t perlin_lds = scene->has_tex && scene->n_perlins != 0 && K.perlin_lds != 0u ? 1536 * sizeof(float) : 0;
     P.perlin_in_lds = perlin_lds != 0 ? 1u : 0u;
     // Block shape: a block is 4, 8, 12 or 16 waves (1 to 4 per SIMD).  The variant's register count says how many waves a
     // SIMD can hold (512 VGPRs each, allocated in eights); take the shape that makes the most waves resident within
@@ -1052,48 +1175,64 @@ extern "C" int rtx_render_accumulate(const rtx_scene_t* scene_c, const rtx_camer
         }
     }
     if (best_resident == 0) return fail(RTX_ERR_DEVICE, "internal: no block shape fits");
-    wpb = std::min<uint32_t>(MAX_WAVES_PER_BLOCK, std::max<uint32_t>(4u, env_u32("RTX_WAVES_PER_BLOCK", wpb) & ~3u));
-    blocks_per_cu = env_u32("RTX_BLOCKS_PER_CU", blocks_per_cu);
+    if (K.waves_per_block != 0u) wpb = std::min<uint32_t>(MAX_WAVES_PER_BLOCK, std::max<uint32_t>(4u, K.waves_per_block & ~3u));
+    if (K.blocks_per_cu != 0u) blocks_per_cu = K.blocks_per_cu;
     lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * 2 * ACC_FLOATS * sizeof(float) + perlin_lds;
-    dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)scene->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
-    if (env_u32("RTX_DEBUG", 0))
+    dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)c->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
+    if (K.debug)
         std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u batches of %u spp, %u items\n", vgprs, wpb,
                      blocks_per_cu, lds, P.n_batches, P.batch, P.n_items);
 
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
-    HIP_TRY(hipEventRecord(scene->ev0, st));
+    HIP_TRY(hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(kern, grid, block, lds, st, P);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(scene->ev1, st));
+    HIP_TRY(hipEventRecord(c->ev1, st));
     {
         dim3 rb(256), rg((unsigned)((npix3 + 255) / 256));
-        hipLaunchKernelGGL(reduce_kernel, rg, rb, 0, st, (const float*)scene->partial, P.n_batches, npix3, accum_dev, cam->width, P.tiles_x, P.tile_rank,
+        hipLaunchKernelGGL(reduce_kernel, rg, rb, 0, st, (const float*)P.partial, P.n_batches, npix3, accum_dev, cam->width, P.tiles_x, P.tile_rank,
                            P.tile_world);
         HIP_TRY(hipGetLastError());
     }
     if (stats) {
         HIP_TRY(hipStreamSynchronize(st));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
-        unsigned long long nrays = 0;
-        HIP_TRY(hipMemcpy(&nrays, scene->counters + 2, 8, hipMemcpyDeviceToHost));
-        stats->samples = (uint64_t)cam->width * cam->height * spp;
-        stats->rays = nrays;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        unsigned long long cnt[3] = {0, 0, 0};  // rays, box tests, primitive tests
+        HIP_TRY(hipMemcpy(cnt, scratch->counters + 2, sizeof(cnt), hipMemcpyDeviceToHost));
+        uint64_t pixels = 0;  // of the tiles this call owns (edge tiles are ragged)
+        for (uint32_t t = P.tile_rank; t < n_tiles; t += P.tile_world) {
+            const uint32_t tx = (t % P.tiles_x) * TILE, ty = (t / P.tiles_x) * TILE;
+            pixels += (uint64_t)std::min<uint32_t>(TILE, cam->width - tx) * std::min<uint32_t>(TILE, cam->height - ty);
+        }
+        stats->samples = pixels * spp;
+        stats->rays = cnt[0];
+        stats->box_tests = cnt[1];
+        stats->prim_tests = cnt[2];
         stats->kernel_ms = ms;
         stats->n_launches = 1;
+        stats->flags = in_lds ? 1u : 0u;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 #ifdef RTX_STAGE_COUNTERS
         unsigned long long sc[12];
-        HIP_TRY(hipMemcpy(sc, scene->counters + 4, 96, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sc, scratch->counters + 2 + 6, 96, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[stage clocks] box %.1f%% primitive %.1f%% service %.1f%% scheduling and item turnover %.1f%% of the waves' time\n", 100.0 * sc[8] / sc[11],
                      100.0 * sc[9] / sc[11], 100.0 * sc[10] / sc[11], 100.0 * (sc[11] - sc[8] - sc[9] - sc[10]) / sc[11]);
-        double r = (double)nrays;
+        double r = (double)cnt[0];
         std::fprintf(stderr, "[stages] rays %.3g | box steps %.3g lanes/step %.1f tests/ray %.2f | prim steps %.3g lanes/step %.1f tests/ray %.2f | service %.3g shade lanes/pass %.1f gen lanes/pass %.1f | sched passes %.3g\n", r,
                      (double)sc[0], (double)sc[1] / sc[0], sc[1] / r, (double)sc[2], (double)sc[3] / sc[2], sc[3] / r, (double)sc[4], (double)sc[5] / sc[4], (double)sc[6] / sc[4], (double)sc[7]);
 #endif
     }
     return RTX_OK;
+}
+
+extern "C" int rtx_render_accumulate(rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, float* accum_dev, void* stream,
+                                     rtx_stats_t* stats) {
+    if (!scene) return fail(RTX_ERR_INVALID, "null argument");
+    DeviceCopy* c = &scene->primary;
+    Scratch scratch{c->partial, c->partial_bytes, c->counters, true};
+    return render_accumulate_on(scene, c, cam, opts, accum_dev, (hipStream_t)stream, stats, &scratch, true);
 }
 
 extern "C" int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float scale, uint8_t* rgb8_dev, void* stream) {
@@ -1106,13 +1245,14 @@ extern "C" int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t heig
     return RTX_OK;
 }
 
-extern "C" int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, uint8_t* rgb8_out, float* accum_out,
+extern "C" int rtx_render(rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, uint8_t* rgb8_out, float* accum_out,
                           rtx_stats_t* stats) {
     if (!scene || !opts || !rgb8_out) return fail(RTX_ERR_INVALID, "null argument");
+    if (opts->n_gpus > 1u) return rtx_render_multi(scene, cam, opts, nullptr, opts->n_gpus, opts->split, rgb8_out, accum_out, stats);
     int rc = check_camera(cam);
     if (rc != RTX_OK) return rc;
     auto t_start = std::chrono::steady_clock::now();
-    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipSetDevice(scene->primary.device));
     const size_t n = (size_t)cam->width * cam->height * 3;
     float* accum = nullptr;
     uint8_t* rgb = nullptr;
@@ -1125,6 +1265,7 @@ extern "C" int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* cam, con
     rtx_render_opts_t o = *opts;
     if (o.sample_begin == 0 && o.sample_end == 0) o.sample_end = cam->samples_per_pixel;
     rtx_stats_t local;
+    std::memset(&local, 0, sizeof(local));
     e = hipMemset(accum, 0, n * sizeof(float));
     if (e == hipSuccess) {
         rc = rtx_render_accumulate(scene, cam, &o, accum, nullptr, &local);
@@ -1141,6 +1282,252 @@ extern "C" int rtx_render(const rtx_scene_t* scene, const rtx_camera_t* cam, con
     if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     if (stats) {
         *stats = local;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    return RTX_OK;
+}
+
+// ================================================================================================ several devices
+// A second copy of the primary's device data on the current device (device-to-device copies), pointers re-based.
+static int replicate(const rtx_scene* scene, DeviceCopy* r) {
+    const DeviceCopy& p = scene->primary;
+    HIP_TRY(hipGetDevice(&r->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950");
+    r->n_cus = prop.multiProcessorCount;
+    if (r->device != p.device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, r->device, p.device) == hipSuccess && can) {
+            hipError_t e = hipDeviceEnablePeerAccess(p.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies then go through the host
+        }
+        (void)hipGetLastError();
+    }
+    for (const auto& a : p.allocs) {
+        void* q = nullptr;
+        HIP_TRY(hipMalloc(&q, a.second));
+        r->allocs.emplace_back(q, a.second);
+        HIP_TRY(hipMemcpyPeer(q, r->device, a.first, p.device, a.second));
+    }
+    auto rebase = [&](const void* old) -> void* {
+        for (size_t i = 0; i < p.allocs.size(); i++)
+            if (p.allocs[i].first == old) return r->allocs[i].first;
+        return nullptr;
+    };
+    r->dev = p.dev;
+#define RTX_REBASE(field)                                                                        \
+    do {                                                                                         \
+        void* q_ = rebase((const void*)p.dev.field);                                             \
+        if (!q_) return fail(RTX_ERR_DEVICE, "internal: device pointer outside the scene's allocations"); \
+        r->dev.field = static_cast<std::remove_reference_t<decltype(r->dev.field)>>(q_);         \
+    } while (0)
+    for (int m = 0; m < 2; m++) {
+        RTX_REBASE(ents[m]);
+        RTX_REBASE(rank[m]);
+        RTX_REBASE(shade[m]);
+    }
+    RTX_REBASE(sph);
+    RTX_REBASE(sph_id);
+    RTX_REBASE(planar);
+    RTX_REBASE(planar_id);
+    RTX_REBASE(mats);
+    RTX_REBASE(texs);
+    RTX_REBASE(images);
+    RTX_REBASE(perlin);
+#undef RTX_REBASE
+    if (scene->n_images != 0) {  // the image table itself holds device pointers
+        std::vector<DevImage> im(scene->n_images);
+        HIP_TRY(hipMemcpy(im.data(), r->dev.images, im.size() * sizeof(DevImage), hipMemcpyDeviceToHost));
+        for (DevImage& x : im) {
+            void* q = rebase(x.rgb);
+            if (!q) return fail(RTX_ERR_DEVICE, "internal: image raster outside the scene's allocations");
+            x.rgb = reinterpret_cast<const uint8_t*>(q);
+        }
+        HIP_TRY(hipMemcpy(const_cast<DevImage*>(r->dev.images), im.data(), im.size() * sizeof(DevImage), hipMemcpyHostToDevice));
+    }
+    // the copied fast array carries the order the primary's had at this moment
+    std::memcpy(r->view, p.view, sizeof(r->view));
+    r->view_grow = p.view_grow;
+    r->view_valid = p.view_valid;
+    HIP_TRY(hipMalloc((void**)&r->counters, COUNTER_BYTES));
+    HIP_TRY(hipEventCreate(&r->ev0));
+    HIP_TRY(hipEventCreate(&r->ev1));
+    return RTX_OK;
+}
+
+template <class T>
+static int ensure_buffer(T** buf, size_t* have, size_t need) {
+    if (*have >= need) return RTX_OK;
+    if (*buf) hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc((void**)buf, need));
+    *have = need;
+    return RTX_OK;
+}
+
+__global__ __launch_bounds__(256) void add_slots_kernel(float* __restrict__ dst, const float* __restrict__ slots, uint32_t n_slots, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = dst[i];
+    for (uint32_t k = 0; k < n_slots; k++) s += slots[(size_t)k * n + i];  // device order: the sum does not depend on arrival order
+    dst[i] = s;
+}
+
+// Keeps, per pixel, the bytes of the one share that owns the pixel's tile.
+__global__ __launch_bounds__(256) void merge_tiles_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ slots, uint32_t n_shares, size_t n,
+                                                          uint32_t width, uint32_t tiles_x) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pix = (uint32_t)(i / 3), px = pix % width, py = pix / width;
+    const uint32_t owner = ((py / TILE) * tiles_x + px / TILE) % n_shares;
+    if (owner != 0u) dst[i] = slots[(size_t)(owner - 1u) * n + i];
+}
+
+extern "C" int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, const int* devices, uint32_t n_devices,
+                                uint32_t split, uint8_t* rgb8_out, float* accum_out, rtx_stats_t* stats) {
+    if (!scene || !opts || !rgb8_out) return fail(RTX_ERR_INVALID, "null argument");
+    int rc = check_camera(cam);
+    if (rc != RTX_OK) return rc;
+    if (n_devices == 0 || n_devices > 64) return fail(RTX_ERR_INVALID, "n_devices must be 1..64");
+    if (split > RTX_SPLIT_TILES) return fail(RTX_ERR_INVALID, "unknown split");
+    if (opts->tile_world > 1u) return fail(RTX_ERR_INVALID, "tile_rank / tile_world belong to rtx_render_accumulate; rtx_render_multi assigns the shares itself");
+    auto t_start = std::chrono::steady_clock::now();
+    int n_visible = 0;
+    HIP_TRY(hipGetDeviceCount(&n_visible));
+    std::vector<int> dev(n_devices);
+    for (uint32_t k = 0; k < n_devices; k++) {
+        dev[k] = devices ? devices[k] : (int)k;
+        if (dev[k] < 0 || dev[k] >= n_visible) return fail(RTX_ERR_NO_DEVICE, "device ordinal out of range: fewer GPUs are visible than the call names");
+    }
+    uint32_t sb = opts->sample_begin, se = opts->sample_end;
+    if (sb == 0 && se == 0) se = cam->samples_per_pixel;
+    if (se < sb) return fail(RTX_ERR_INVALID, "sample_end < sample_begin");
+    const uint32_t spp = se - sb;
+    const size_t n = (size_t)cam->width * cam->height * 3;
+    const bool bytes_only = split == RTX_SPLIT_TILES && accum_out == nullptr;  // a tile's owner resolves it; only RGB8 travels
+
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    struct Restore {
+        int d;
+        ~Restore() { hipSetDevice(d); }
+    } restore{prev};
+
+    // share k runs on copy k: the primary when it lives on the share's device and no earlier share took it
+    if (scene->replicas.size() < n_devices) scene->replicas.resize(n_devices, nullptr);
+    std::vector<DeviceCopy*> copy(n_devices, nullptr);
+    bool primary_taken = false;
+    for (uint32_t k = 0; k < n_devices; k++) {
+        HIP_TRY(hipSetDevice(dev[k]));
+        if (!primary_taken && dev[k] == scene->primary.device) {
+            copy[k] = &scene->primary;
+            primary_taken = true;
+        } else {
+            DeviceCopy*& r = scene->replicas[k];
+            if (r && r->device != dev[k]) {
+                release_copy(r);
+                delete r;
+                r = nullptr;
+                HIP_TRY(hipSetDevice(dev[k]));
+            }
+            if (!r) {
+                r = new DeviceCopy();
+                if ((rc = replicate(scene, r)) != RTX_OK) {
+                    std::string keep = g_err;
+                    release_copy(r);
+                    delete r;
+                    r = nullptr;
+                    g_err = keep;
+                    return rc;
+                }
+            }
+            copy[k] = r;
+        }
+        DeviceCopy* c = copy[k];
+        if (!c->stream) HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        if (!c->done) HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+        if ((rc = ensure_buffer(&c->accum, &c->accum_bytes, n * sizeof(float))) != RTX_OK) return rc;
+        if ((rc = ensure_buffer(&c->rgb, &c->rgb_bytes, n)) != RTX_OK) return rc;
+    }
+    DeviceCopy* root = copy[0];
+    HIP_TRY(hipSetDevice(dev[0]));
+    const size_t slot_bytes = bytes_only ? n : n * sizeof(float);
+    if (n_devices > 1 && (rc = ensure_buffer((char**)&root->staging, &root->staging_bytes, slot_bytes * (n_devices - 1))) != RTX_OK) return rc;
+
+    // launch every share on its own device and stream, then push its result into its slot on the first device
+    std::vector<rtx_stats_t> st(n_devices);
+    for (uint32_t k = 0; k < n_devices; k++) {
+        DeviceCopy* c = copy[k];
+        HIP_TRY(hipSetDevice(dev[k]));
+        rtx_render_opts_t o = *opts;
+        o.n_gpus = 0;
+        if (split == RTX_SPLIT_SAMPLES) {
+            o.sample_begin = sb + (uint32_t)(((uint64_t)k * spp) / n_devices);
+            o.sample_end = sb + (uint32_t)(((uint64_t)(k + 1) * spp) / n_devices);
+            o.tile_rank = 0;
+            o.tile_world = 1;
+        } else {
+            o.sample_begin = sb;
+            o.sample_end = se;
+            o.tile_rank = k;
+            o.tile_world = n_devices;
+        }
+        HIP_TRY(hipMemsetAsync(c->accum, 0, n * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->counters, 0, COUNTER_BYTES, c->stream));  // a share with nothing to render launches nothing
+        Scratch scratch{c->partial, c->partial_bytes, c->counters, true};
+        if ((rc = render_accumulate_on(scene, c, cam, &o, c->accum, c->stream, nullptr, &scratch, true)) != RTX_OK) return rc;
+        if (bytes_only) {
+            if ((rc = rtx_resolve(c->accum, cam->width, cam->height, cam->pixel_samples_scale, c->rgb, c->stream)) != RTX_OK) return rc;
+            if (k > 0) HIP_TRY(hipMemcpyPeerAsync((char*)root->staging + (size_t)(k - 1) * slot_bytes, dev[0], c->rgb, dev[k], slot_bytes, c->stream));
+        } else if (k > 0) {
+            HIP_TRY(hipMemcpyPeerAsync((char*)root->staging + (size_t)(k - 1) * slot_bytes, dev[0], c->accum, dev[k], slot_bytes, c->stream));
+        }
+        HIP_TRY(hipEventRecord(c->done, c->stream));
+    }
+    // the first device waits for every slot, combines them in device order and resolves
+    HIP_TRY(hipSetDevice(dev[0]));
+    for (uint32_t k = 1; k < n_devices; k++) HIP_TRY(hipStreamWaitEvent(root->stream, copy[k]->done, 0));
+    {
+        dim3 b(256), g((unsigned)((n + 255) / 256));
+        if (bytes_only) {
+            if (n_devices > 1) {
+                hipLaunchKernelGGL(merge_tiles_kernel, g, b, 0, root->stream, root->rgb, (const uint8_t*)root->staging, n_devices, n, cam->width,
+                                   (cam->width + TILE - 1) / TILE);
+                HIP_TRY(hipGetLastError());
+            }
+        } else {
+            if (n_devices > 1) {
+                hipLaunchKernelGGL(add_slots_kernel, g, b, 0, root->stream, root->accum, (const float*)root->staging, n_devices - 1, n);
+                HIP_TRY(hipGetLastError());
+            }
+            if ((rc = rtx_resolve(root->accum, cam->width, cam->height, cam->pixel_samples_scale, root->rgb, root->stream)) != RTX_OK) return rc;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(rgb8_out, root->rgb, n, hipMemcpyDeviceToHost, root->stream));
+    if (accum_out) HIP_TRY(hipMemcpyAsync(accum_out, root->accum, n * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (uint32_t k = 0; k < n_devices; k++) {
+            DeviceCopy* c = copy[k];
+            HIP_TRY(hipSetDevice(dev[k]));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            unsigned long long cnt[3] = {0, 0, 0};
+            HIP_TRY(hipMemcpy(cnt, c->counters + 2, sizeof(cnt), hipMemcpyDeviceToHost));
+            float ms = 0;
+            if (cnt[0] != 0 && hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) {
+                (void)hipGetLastError();
+                ms = 0;
+            }
+            stats->rays += cnt[0];
+            stats->box_tests += cnt[1];
+            stats->prim_tests += cnt[2];
+            stats->kernel_ms = std::max(stats->kernel_ms, (double)ms);
+            stats->n_launches += 1;
+        }
+        stats->samples = (uint64_t)cam->width * cam->height * spp;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     }
     return RTX_OK;

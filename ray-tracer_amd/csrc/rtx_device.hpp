@@ -56,6 +56,9 @@ __device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
 // ---------------------------------------------------------------------------------------------- random stream
 // 32-bit PCG (RXS-M-XS output) with a per-stream increment.  The stream is a pure function of
 // (seed, pixel index, sample index); draw k of a stream is the k-th step from that state.
+// The 64-bit seed enters as two words k0, k1, each a hash of both of its halves (seed_word on the host).  State and
+// increment come from two separate hash chains over (key, pixel, sample), so that a seed does not merely permute the
+// stream set over the pixels and state and increment are not functions of one 32-bit value.
 struct Rng {
     uint32_t state, inc;
 };
@@ -64,12 +67,10 @@ __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
     uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;
 }
-__device__ __forceinline__ Rng rng_init(uint64_t seed, uint32_t pixel, uint32_t sample) {
+__device__ __forceinline__ Rng rng_init(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample) {
     Rng r;
-    uint32_t h = pcg_hash((uint32_t)seed ^ pixel);
-    h = pcg_hash(h + sample * 0x9E3779B9u);
-    r.state = h;
-    r.inc = (pcg_hash(h ^ (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu) << 1) | 1u;
+    r.state = pcg_hash(pcg_hash(k0 + pixel) + sample * 0x9E3779B9u);
+    r.inc = (pcg_hash(pcg_hash(k1 ^ pixel) + sample * 0x85EBCA6Bu) << 1) | 1u;
     return r;
 }
 __device__ __forceinline__ uint32_t rng_u32(Rng& r) {
@@ -123,9 +124,18 @@ template <int SLAB>
 __device__ __forceinline__ RayConst ray_const(const Ray& r) {
     RayConst c;
     if (SLAB == SLAB_FMA) {
-        c.ix = __builtin_amdgcn_rcpf(r.dx);
-        c.iy = __builtin_amdgcn_rcpf(r.dy);
-        c.iz = __builtin_amdgcn_rcpf(r.dz);
+        // A component of exactly 0 would give inv = inf and -(origin * inv) = -+inf, and bound * inf + -inf is NaN for
+        // one plane only: the axis would cull boxes that straddle the ray.  Components below 1e-22 in magnitude are
+        // therefore taken as +-1e-22: the axis then yields plane distances of +-1e22 x (bound - origin), far beyond any
+        // interval end when the origin is inside the slab and culling when it is outside, which is the exact answer,
+        // and bound * inv stays finite for coordinates up to 1e12.
+        const float tiny = 1e-22f;
+        const float dx = fabsf(r.dx) < tiny ? copysignf(tiny, r.dx) : r.dx;
+        const float dy = fabsf(r.dy) < tiny ? copysignf(tiny, r.dy) : r.dy;
+        const float dz = fabsf(r.dz) < tiny ? copysignf(tiny, r.dz) : r.dz;
+        c.ix = __builtin_amdgcn_rcpf(dx);
+        c.iy = __builtin_amdgcn_rcpf(dy);
+        c.iz = __builtin_amdgcn_rcpf(dz);
         c.nx = -(r.ox * c.ix);
         c.ny = -(r.oy * c.iy);
         c.nz = -(r.oz * c.iz);
@@ -255,10 +265,10 @@ __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, u
 }
 
 // One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
-template <bool STRICT>
+template <bool STRICT, int SLAB>
 __device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t off, const Ray& r, const RayConst& rc,
                                               float tmin, Best& best, const uint32_t* __restrict__ rank) {
-    if (eb.w == ENT_BOX) return slab_hit<STRICT ? SLAB_STRICT : SLAB_ROBUST>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
+    if (eb.w == ENT_BOX) return slab_hit<SLAB>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
     const uint32_t kind = eb.w & 15u;
     if (kind == ENT_SPHERE) {
         sphere_test<STRICT>(ea, eb, r, rc, tmin, best, off, rank);

@@ -149,7 +149,7 @@ int rth_scene_upload(rth_scene* s) {
     if (rc != RTX_OK) g_err = rtx_last_error();
     return rc;
 }
-const rtx_scene_t* rth_scene_device(rth_scene* s) { return s->dev; }
+rtx_scene_t* rth_scene_device(rth_scene* s) { return s->dev; }
 void rth_scene_free(rth_scene* s) {
     if (!s) return;
     if (s->dev) rtx_scene_destroy(s->dev);

@@ -3,6 +3,7 @@
 #include "ray_tracing.hpp"
 
 #include <algorithm>
+#include <future>
 
 namespace ray_tracing {
 
@@ -287,29 +288,51 @@ static inline int32_t total_key(float f) {
     v ^= (int32_t)(((uint32_t)(v >> 31)) >> 1);
     return v;
 }
-std::shared_ptr<Bvh> Bvh::from(const std::vector<MeshP>& value) {
-    if (value.empty()) throw std::invalid_argument("Bvh::from: empty slice (the reference recurses without bound)");
+// Bvh::from (mesh.rs:564-604).  The reference clones the slice, sorts the clone and recurses into clones of its halves;
+// sorting a sub-range of one working array in place gives the same order (each recursion only ever reads its own
+// range, and the sort is stable over the order its parent left), without copying reference-counted pointers at every
+// level.  Large ranges build their two halves on separate threads: the halves are independent, so the tree is the same.
+namespace {
+struct BvhItem {
+    const MeshP* mesh;
+    const Aabb* box;
+    int32_t key;
+};
+std::shared_ptr<Bvh> bvh_build(BvhItem* begin, BvhItem* end, int depth) {
+    const size_t n = (size_t)(end - begin);
     auto node = std::make_shared<Bvh>();
     Aabb box;  // Aabb::default() = 0..0 on every axis: node boxes always contain the origin
-    for (const MeshP& m : value) box = box.merge(m->bounding_box());
+    for (BvhItem* it = begin; it != end; ++it) box = box.merge(*it->box);
     node->bbox = box;
-    int axis = box.longest_axis();
-    if (value.size() == 1) {
-        node->left = value[0];
-        node->right = value[0];
-    } else if (value.size() == 2) {
-        node->left = value[0];
-        node->right = value[1];
+    const int axis = box.longest_axis();
+    if (n == 1) {
+        node->left = *begin->mesh;
+        node->right = *begin->mesh;
+    } else if (n == 2) {
+        node->left = *begin[0].mesh;
+        node->right = *begin[1].mesh;
     } else {
-        std::vector<MeshP> v(value);
-        std::stable_sort(v.begin(), v.end(), [axis](const MeshP& a, const MeshP& b) {
-            return total_key(a->bounding_box()[axis].start) < total_key(b->bounding_box()[axis].start);
-        });
-        size_t mid = v.size() / 2;
-        node->left = from(std::vector<MeshP>(v.begin(), v.begin() + mid));
-        node->right = from(std::vector<MeshP>(v.begin() + mid, v.end()));
+        for (BvhItem* it = begin; it != end; ++it) it->key = total_key((*it->box)[axis].start);
+        std::stable_sort(begin, end, [](const BvhItem& a, const BvhItem& b) { return a.key < b.key; });
+        BvhItem* mid = begin + n / 2;
+        if (n >= (1u << 16) && depth < 5) {
+            auto left = std::async(std::launch::async, bvh_build, begin, mid, depth + 1);
+            node->right = bvh_build(mid, end, depth + 1);
+            node->left = left.get();
+        } else {
+            node->left = bvh_build(begin, mid, depth + 1);
+            node->right = bvh_build(mid, end, depth + 1);
+        }
     }
     return node;
+}
+}  // namespace
+
+std::shared_ptr<Bvh> Bvh::from(const std::vector<MeshP>& value) {
+    if (value.empty()) throw std::invalid_argument("Bvh::from: empty slice (the reference recurses without bound)");
+    std::vector<BvhItem> items(value.size());
+    for (size_t i = 0; i < value.size(); i++) items[i] = BvhItem{&value[i], &value[i]->bounding_box(), 0};
+    return bvh_build(items.data(), items.data() + items.size(), 0);
 }
 rtx_ref_t Bvh::flatten(SceneBuilder& b) const {
     return memoized(b, this, [&] {
@@ -377,7 +400,7 @@ GpuScene::~GpuScene() {
     if (scene_) rtx_scene_destroy(scene_);
 }
 
-RgbImage Camera::render(const GpuScene& scene, uint64_t seed, std::vector<float>* accum, rtx_stats_t* stats) const {
+RgbImage Camera::render(const GpuScene& scene, uint64_t seed, std::vector<float>* accum, rtx_stats_t* stats, uint32_t n_gpus, uint32_t split) const {
     RgbImage img;
     img.width = config.width; img.height = config.height;
     img.data.resize((size_t)config.width * config.height * 3);
@@ -386,6 +409,8 @@ RgbImage Camera::render(const GpuScene& scene, uint64_t seed, std::vector<float>
     rtx_render_opts_t opts;
     std::memset(&opts, 0, sizeof(opts));
     opts.seed = seed;
+    opts.n_gpus = n_gpus;
+    opts.split = split;
     int rc = rtx_render(scene.handle(), &cam, &opts, img.data.data(), accum ? accum->data() : nullptr, stats);
     if (rc != RTX_OK) throw std::runtime_error(std::string("rtx_render: ") + rtx_last_error());
     return img;

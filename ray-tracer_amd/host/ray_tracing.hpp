@@ -281,7 +281,7 @@ class GpuScene {
     ~GpuScene();
     GpuScene(const GpuScene&) = delete;
     GpuScene& operator=(const GpuScene&) = delete;
-    const rtx_scene_t* handle() const { return scene_; }
+    rtx_scene_t* handle() const { return scene_; }  // renders re-order the device data for their camera: not const
     const SceneBuilder& flat() const { return builder_; }
 
   private:
@@ -297,7 +297,9 @@ struct Camera {  // camera.rs:45-169
     rtx_camera_t to_ffi() const;
     // Camera::render (camera.rs:98): flatten, upload, path-trace on the GPU, return the image.  Throws on failure.
     RgbImage render(const Mesh& mesh, uint64_t seed = 0) const;
-    RgbImage render(const GpuScene& scene, uint64_t seed = 0, std::vector<float>* accum = nullptr, rtx_stats_t* stats = nullptr) const;
+    // n_gpus > 1: the one blocking call drives GPUs 0 .. n_gpus-1 itself (split = RTX_SPLIT_SAMPLES or RTX_SPLIT_TILES).
+    RgbImage render(const GpuScene& scene, uint64_t seed = 0, std::vector<float>* accum = nullptr, rtx_stats_t* stats = nullptr,
+                    uint32_t n_gpus = 1, uint32_t split = RTX_SPLIT_SAMPLES) const;
 };
 
 // Flatten `root` into `b` (sets b.root).  Throws std::invalid_argument on malformed input.

@@ -21,7 +21,8 @@ from .scene import lower
 F = np.float32
 _DIR = os.path.dirname(os.path.abspath(__file__))
 
-TRAVERSAL_FAST, TRAVERSAL_STRICT = 0, 1
+TRAVERSAL_FAST, TRAVERSAL_STRICT, TRAVERSAL_FAST_FUSED = 0, 1, 2
+SPLIT_SAMPLES, SPLIT_TILES = 0, 1
 RTX_OK, RTX_ERR_INVALID, RTX_ERR_UNSUPPORTED, RTX_ERR_DEVICE, RTX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 
@@ -50,14 +51,14 @@ class RenderOpts(C.Structure):
     """rtx_render_opts_t"""
 
     _fields_ = [("seed", C.c_uint64), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("traversal", C.c_uint32),
-                ("rr_start_depth", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("rr_start_depth", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("n_gpus", C.c_uint32), ("split", C.c_uint32)]
 
 
 class Stats(C.Structure):
     """rtx_stats_t"""
 
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("n_launches", C.c_uint32), ("pad", C.c_uint32)]
+                ("n_launches", C.c_uint32), ("flags", C.c_uint32), ("box_tests", C.c_uint64), ("prim_tests", C.c_uint64)]
 
 
 class BvhNode(C.Structure):
@@ -110,7 +111,7 @@ _host = None
 _rtx = None
 
 RTX_SYMBOLS = ["rtx_device_count", "rtx_last_error", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace", "rtx_trace_device",
-               "rtx_render", "rtx_render_accumulate", "rtx_resolve", "rtx_traversal_dump"]
+               "rtx_render", "rtx_render_multi", "rtx_render_accumulate", "rtx_resolve", "rtx_traversal_dump"]
 
 
 def rtx():
@@ -130,6 +131,7 @@ def rtx():
     L.rtx_trace.argtypes = [V, V, C.c_size_t, C.POINTER(TraceOpts), V]
     L.rtx_trace_device.argtypes = [V, V, C.c_size_t, C.POINTER(TraceOpts), V, V]
     L.rtx_render.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
+    L.rtx_render_multi.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, V, V, C.POINTER(Stats)]
     L.rtx_render_accumulate.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
     L.rtx_resolve.argtypes = [V, C.c_uint32, C.c_uint32, C.c_float, V, V]
     L.rtx_traversal_dump.argtypes = [C.POINTER(SceneDesc), C.c_uint32, capi.c_float_p, C.c_float, capi.c_u32_p, capi.c_u32_p, C.c_size_t,
@@ -269,15 +271,24 @@ class Camera:
         d["pixel_samples_scale"] = F(f.pixel_samples_scale)
         return d
 
-    def render(self, scene, seed=0, traversal=TRAVERSAL_FAST, rr_start_depth=0, want_accum=False, want_stats=False):
-        """Whole-frame render through rtx_render (host buffers). Returns rgb8 [H,W,3] (+ accum [H,W,3] f32 sums, + Stats)."""
+    def render(self, scene, seed=0, traversal=TRAVERSAL_FAST, rr_start_depth=0, want_accum=False, want_stats=False, n_gpus=1,
+               split=SPLIT_SAMPLES, devices=None):
+        """Whole-frame render through rtx_render (host buffers). Returns rgb8 [H,W,3] (+ accum [H,W,3] f32 sums, + Stats).
+        n_gpus > 1: the one call drives GPUs 0 .. n_gpus-1; devices=[...] names them explicitly (rtx_render_multi; an
+        ordinal may repeat to rehearse the multi-GPU path on one GPU)."""
         h, w = self.cfg.height, self.cfg.width
         rgb = np.zeros((h, w, 3), dtype=np.uint8)
         accum = np.zeros((h, w, 3), dtype=F) if want_accum else None
-        opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth)
         st = Stats()
-        _check(rtx().rtx_render(scene.device, C.byref(self.ffi), C.byref(opts), rgb.ctypes.data,
-                                accum.ctypes.data if want_accum else None, C.byref(st)))
+        if devices is not None:
+            opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth)
+            ids = (C.c_int * len(devices))(*devices)
+            _check(rtx().rtx_render_multi(scene.device, C.byref(self.ffi), C.byref(opts), ids, len(devices), split, rgb.ctypes.data,
+                                          accum.ctypes.data if want_accum else None, C.byref(st)))
+        else:
+            opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth, 0, 0, n_gpus, split)
+            _check(rtx().rtx_render(scene.device, C.byref(self.ffi), C.byref(opts), rgb.ctypes.data,
+                                    accum.ctypes.data if want_accum else None, C.byref(st)))
         out = [rgb]
         if want_accum:
             out.append(accum)

@@ -16,7 +16,8 @@ from .scene import (Bvh, CameraConfig, CheckerTexture, ConstantMedium, Cube, Die
                     Lambertian, Metal, NoiseTexture, Quad, RotateY, SolidTexture, Sphere, Translate, TriangleMesh, World, vec3)
 
 F = np.float32
-_EARTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "earthmap_rgb8.png")
+# decoded raster of the reference's images/earthmap.jpg (1024x512 RGB8), shipped with the package
+_EARTH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "earthmap_rgb8.png")
 
 X, Y, Z = vec3(1, 0, 0), vec3(0, 1, 0), vec3(0, 0, 1)
 

@@ -197,8 +197,14 @@ pub struct rtx_render_opts_t {
     pub rr_start_depth: u32,
     pub tile_rank: u32,
     pub tile_world: u32,
-    pub reserved: [u32; 2],
+    /// rtx_render only: 0 or 1 = the scene's device; N > 1 = devices 0..N-1, driven from the one call.
+    pub n_gpus: u32,
+    /// RTX_SPLIT_SAMPLES (0) or RTX_SPLIT_TILES (1) when n_gpus > 1.
+    pub split: u32,
 }
+
+pub const RTX_SPLIT_SAMPLES: u32 = 0;
+pub const RTX_SPLIT_TILES: u32 = 1;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -208,7 +214,10 @@ pub struct rtx_stats_t {
     pub kernel_ms: f64,
     pub total_ms: f64,
     pub n_launches: u32,
-    pub pad: u32,
+    /// bit 0: the traversal entries were resident in LDS
+    pub flags: u32,
+    pub box_tests: u64,
+    pub prim_tests: u64,
 }
 
 #[repr(C)]
@@ -224,9 +233,12 @@ extern "C" {
     pub fn rtx_trace(scene: *const rtx_scene_t, rays: *const rtx_ray_t, n: usize, opts: *const rtx_trace_opts_t, hits_out: *mut rtx_hit_t) -> c_int;
     pub fn rtx_trace_device(scene: *const rtx_scene_t, rays_dev: *const rtx_ray_t, n: usize, opts: *const rtx_trace_opts_t, hits_dev: *mut rtx_hit_t,
                             stream: *mut c_void) -> c_int;
-    pub fn rtx_render(scene: *const rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, rgb8_out: *mut u8, accum_out: *mut f32,
+    pub fn rtx_render(scene: *mut rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, rgb8_out: *mut u8, accum_out: *mut f32,
                       stats: *mut rtx_stats_t) -> c_int;
-    pub fn rtx_render_accumulate(scene: *const rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, accum_dev: *mut f32,
+    /// One blocking call that drives several GPUs (devices == null: 0..n_devices-1).
+    pub fn rtx_render_multi(scene: *mut rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, devices: *const c_int,
+                            n_devices: u32, split: u32, rgb8_out: *mut u8, accum_out: *mut f32, stats: *mut rtx_stats_t) -> c_int;
+    pub fn rtx_render_accumulate(scene: *mut rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, accum_dev: *mut f32,
                                  stream: *mut c_void, stats: *mut rtx_stats_t) -> c_int;
     pub fn rtx_resolve(accum_dev: *const f32, width: u32, height: u32, scale: f32, rgb8_dev: *mut u8, stream: *mut c_void) -> c_int;
     /// Host-only inspection of the traversal data (no device is touched).

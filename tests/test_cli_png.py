@@ -94,10 +94,10 @@ def test_bench_two_ranks_render_the_single_rank_frame(tmp_path, split):
     one = tmp_path / "one.png"
     out1 = subprocess.check_output([sys.executable, "bench.py", "--gpus", "1", "--save", str(one)] + common, cwd=ROOT, timeout=300)
     two = tmp_path / "two.png"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out2 = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                    "--master-port", "29533" if split == "spp" else "29534", "bench.py", "--gpus", "2", "--backend", "gloo", "--one-device",
-                                    "--split", split, "--save", str(two)] + common, cwd=ROOT, timeout=600, env=env)
+    # no launcher: `python bench.py --gpus 2` starts its own ranks (one process per GPU) before it touches the GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out2 = subprocess.check_output([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--one-device", "--split", split, "--save", str(two)]
+                                   + common, cwd=ROOT, timeout=600, env=env)
     a, b = png.decode_rgb8(one.read_bytes()), png.decode_rgb8(two.read_bytes())
     assert a.shape == b.shape == (180, 320, 3)
     diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
@@ -107,3 +107,13 @@ def test_bench_two_ranks_render_the_single_rank_frame(tmp_path, split):
         d = json.loads(line)
         assert d["n_gpus"] == n and d["unit"] == "Msamples/s" and d["value"] > 0 and d["scaling"] == "strong"
         assert d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
+        assert d["box_tests_per_ray"] > 1 and d["prim_tests_per_ray"] > 0.1
+    # the same two shares behind the C ABI: one process, rtx_render_multi
+    three = tmp_path / "three.png"
+    out3 = subprocess.check_output([sys.executable, "bench.py", "--gpus", "2", "--in-library", "--one-device", "--split", split, "--save", str(three)]
+                                   + common, cwd=ROOT, timeout=600, env=env)
+    c = png.decode_rgb8(three.read_bytes())
+    diff = np.abs(a.astype(np.int32) - c.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 0.01
+    d = json.loads([l for l in out3.decode().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and "rtx_render_multi" in d["config"]["parallelism"]
