@@ -206,7 +206,7 @@ def test_fused_box_test_on_axis_parallel_rays(render, oracle, scenes, capi):
     same = fused["prim_id"] == want["prim_id"]
     assert np.mean(same) > 0.999, float(np.mean(same))
     assert np.array_equal(fused["t"][same & (want["prim_id"] != MISS)], want["t"][same & (want["prim_id"] != MISS)])
-    assert np.count_nonzero(want["prim_id"] != MISS) > n // 2
+    assert np.count_nonzero(want["prim_id"] != MISS) > n // 4
     # general rays as well: primary and surface-origin secondary rays of two more scenes
     for name, seed in (("quads", 0), ("triangle-mesh", 1)):
         cfg, bvh = scenes.make(name, seed=seed, width=160, height=90)
