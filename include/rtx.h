@@ -294,6 +294,21 @@ int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_r
 int rtx_render_accumulate(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
                           float* accum_dev, void* stream, rtx_stats_t* stats);
 
+/* The same call for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Everything rtx_render_accumulate keeps
+ * in library-owned device memory -- the per-batch partial images and the work counters -- lives in one fixed array
+ * of RTX_STATIC_SCRATCH_BYTES inside the library's code object (one copy per GPU, held until the process ends), and
+ * the call performs no hipMalloc / hipFree and no upload: it fails with RTX_ERR_UNSUPPORTED when
+ * 12 * width * height bytes (one partial image) exceed the array, and when the scene's fast traversal data has not
+ * been prepared for this camera position by an earlier rtx_render_accumulate / rtx_render with the same camera
+ * centre (RTX_TRAVERSAL_STRICT needs no preparation).  Frames are cut into as many sample batches as fit the array,
+ * so results equal rtx_render_accumulate's up to the order of fp32 additions.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams or threads) race.  With stats non-null the call
+ * synchronises the stream. */
+#define RTX_STATIC_SCRATCH_BYTES (64u << 20)
+int rtx_render_accumulate_static(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
+                                 float* accum_dev, void* stream, rtx_stats_t* stats);
+
 /* camera.rs:101, :119: rgb8 = round(clamp(srgb_oetf(accum * scale), 0, 1) * 255).  Device buffers. */
 int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float scale, uint8_t* rgb8_dev,
                 void* stream);

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1233,6 +1234,39 @@ extern "C" int rtx_render_accumulate(rtx_scene_t* scene, const rtx_camera_t* cam
     DeviceCopy* c = &scene->primary;
     Scratch scratch{c->partial, c->partial_bytes, c->counters, true};
     return render_accumulate_on(scene, c, cam, opts, accum_dev, (hipStream_t)stream, stats, &scratch, true);
+}
+
+// ------------------------------------------------------------------------------------------------ fixed scratch
+// The library-owned device memory of rtx_render_accumulate_static: work counters, then the per-batch partial images.
+// One copy of the array exists per GPU the code object is loaded on.  In host code the array's NAME is only a handle for
+// hipGetSymbolAddress: the device address it returns (per device) is what kernels and memsets are given.
+static __device__ __align__(256) unsigned char scratch[COUNTER_BYTES + (size_t)RTX_STATIC_SCRATCH_BYTES];
+constexpr int MAX_SCRATCH_DEVICES = 64;
+static void* g_scratch_addr[MAX_SCRATCH_DEVICES];  // device address of `scratch` on device i, resolved on first use there
+static std::mutex g_scratch_mutex;
+
+extern "C" int rtx_render_accumulate_static(rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, float* accum_dev, void* stream,
+                                            rtx_stats_t* stats) {
+    if (!scene) return fail(RTX_ERR_INVALID, "null argument");
+    DeviceCopy* c = &scene->primary;
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != c->device) return fail(RTX_ERR_INVALID, "scene lives on another device than the current one");
+    if (cur < 0 || cur >= MAX_SCRATCH_DEVICES) return fail(RTX_ERR_UNSUPPORTED, "device ordinal beyond the fixed scratch table");
+    void* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_addr[cur]) {
+            void* p = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));  // the current device's copy
+            if (!p) return fail(RTX_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the scratch array");
+            g_scratch_addr[cur] = p;
+        }
+        base = g_scratch_addr[cur];
+    }
+    Scratch fixed{reinterpret_cast<float*>(static_cast<unsigned char*>(base) + COUNTER_BYTES), (size_t)RTX_STATIC_SCRATCH_BYTES,
+                  static_cast<uint32_t*>(base), false};
+    return render_accumulate_on(scene, c, cam, opts, accum_dev, (hipStream_t)stream, stats, &fixed, false);
 }
 
 extern "C" int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float scale, uint8_t* rgb8_dev, void* stream) {

@@ -111,7 +111,7 @@ _host = None
 _rtx = None
 
 RTX_SYMBOLS = ["rtx_device_count", "rtx_last_error", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace", "rtx_trace_device",
-               "rtx_render", "rtx_render_multi", "rtx_render_accumulate", "rtx_resolve", "rtx_traversal_dump"]
+               "rtx_render", "rtx_render_multi", "rtx_render_accumulate", "rtx_render_accumulate_static", "rtx_resolve", "rtx_traversal_dump"]
 
 
 def rtx():
@@ -133,6 +133,7 @@ def rtx():
     L.rtx_render.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
     L.rtx_render_multi.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, V, V, C.POINTER(Stats)]
     L.rtx_render_accumulate.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
+    L.rtx_render_accumulate_static.argtypes = [V, C.POINTER(CameraFFI), C.POINTER(RenderOpts), V, V, C.POINTER(Stats)]
     L.rtx_resolve.argtypes = [V, C.c_uint32, C.c_uint32, C.c_float, V, V]
     L.rtx_traversal_dump.argtypes = [C.POINTER(SceneDesc), C.c_uint32, capi.c_float_p, C.c_float, capi.c_u32_p, capi.c_u32_p, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
@@ -297,11 +298,13 @@ class Camera:
         return out[0] if len(out) == 1 else tuple(out)
 
     def render_accumulate(self, scene, accum_ptr, sample_begin, sample_end, seed=0, traversal=TRAVERSAL_FAST, rr_start_depth=0,
-                          stream=None, stats=None, tile_rank=0, tile_world=1):
+                          stream=None, stats=None, tile_rank=0, tile_world=1, static=False):
         """rtx_render_accumulate on a device buffer (3*W*H f32) for the sample range [sample_begin, sample_end) of the
-        tiles t with t % tile_world == tile_rank."""
+        tiles t with t % tile_world == tile_rank.  static=True: rtx_render_accumulate_static, the variant that keeps its
+        scratch in a fixed device array and allocates nothing."""
         opts = RenderOpts(seed, sample_begin, sample_end, traversal, rr_start_depth, tile_rank, tile_world)
-        _check(rtx().rtx_render_accumulate(scene.device, C.byref(self.ffi), C.byref(opts), accum_ptr, stream,
+        fn = rtx().rtx_render_accumulate_static if static else rtx().rtx_render_accumulate
+        _check(fn(scene.device, C.byref(self.ffi), C.byref(opts), accum_ptr, stream,
                                            C.byref(stats) if stats is not None else None))
 
     def resolve(self, accum_ptr, rgb8_ptr, scale=None, stream=None):
