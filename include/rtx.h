@@ -198,10 +198,12 @@ typedef struct rtx_hit {
 enum {
     RTX_TRAVERSAL_FAST = 0,  /* library-built SAH BVH over tight boxes, closest hit with the reference's tie-break */
     RTX_TRAVERSAL_STRICT = 1, /* walks bvh_nodes exactly as Bvh::hit does (mesh.rs:608-620), same boxes, same order */
-    RTX_TRAVERSAL_FAST_FUSED = 2 /* rtx_trace only: the fast data walked with the box test the render kernels use
-                                    (one fused multiply-add per plane, hardware reciprocal).  Same hits as FAST for
-                                    ray origins inside the scene's coordinate range or, after a render, within the
-                                    reach of that render's camera: the boxes are padded for exactly that. */
+    RTX_TRAVERSAL_FAST_FUSED = 2 /* rtx_trace / rtx_traversal_dump only: the fast data exactly as the render kernels walk
+                                    it -- the packed form (16-byte slots, half-precision boxes in centre / half-extent
+                                    form) when the scene has no Translate / RotateY / ConstantMedium, else the 32-byte
+                                    entries -- with their box test (fused multiply-adds, hardware reciprocal).  Same
+                                    hits as FAST for ray origins inside the scene's coordinate range or, after a
+                                    render, within the reach of that render's camera: the boxes are padded for that. */
 };
 
 typedef struct rtx_trace_opts {
@@ -317,7 +319,9 @@ int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float s
  * rtx_scene_create builds for `desc` -- 8 words per 32-byte entry as the kernels read them, links as byte offsets,
  * terminator last -- and the tie-break rank per entry.  traversal = RTX_TRAVERSAL_*.  view (nullable, 3 floats): order
  * the fast data for that viewpoint as a render from there would; grow: enlarge every fast box by this much.
- * With entries_out == NULL only *n_entries is set.  Used by the CPU test-suite to walk the data without a GPU. */
+ * With entries_out == NULL only *n_entries is set.  Used by the CPU test-suite to walk the data without a GPU.
+ * RTX_TRAVERSAL_FAST_FUSED dumps the packed form instead: 4 words per 16-byte slot, *n_entries and capacity count
+ * slots, rank_out gets one word per slot (RTX_ERR_UNSUPPORTED for a scene with transforms or media). */
 int rtx_traversal_dump(const rtx_scene_desc_t* desc, uint32_t traversal, const float* view, float grow,
                        uint32_t* entries_out, uint32_t* rank_out, size_t capacity, size_t* n_entries);
 

@@ -140,14 +140,15 @@ static inline Box3 prim_box(const rtx_scene_desc_t& d, uint32_t kind, uint32_t i
 
 // Outward padding of a fast-mode box.  The slab test and the primitive tests round differently, so a box that is
 // exactly tight could cull a ray the primitive test would still accept: 1e-3 of the box diagonal, a few ulps of the
-// coordinates, and the absolute error of the fused box test (~1.2e-7 * (|origin| + |hit point|) <= 2.4e-7 * range).
+// coordinates, and the absolute error of the fused box tests (two rounding steps of ~1.2e-7 * (|origin| + |plane|) each in
+// the centre / half-extent form: <= 4.8e-7 * range).
 static inline void pad_box(Box3& b, float coord_range) {
     float diag2 = 0;
     for (int a = 0; a < 3; a++) diag2 += (b.hi[a] - b.lo[a]) * (b.hi[a] - b.lo[a]);
     float pad = std::isfinite(diag2) ? 1e-3f * std::sqrt(diag2) : 0.0f;
     for (int a = 0; a < 3; a++) {
         float m = std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-        float p = pad + 4e-7f * m + 3e-7f * coord_range + 1e-30f;
+        float p = pad + 6e-7f * m + 5e-7f * coord_range + 1e-30f;
         b.lo[a] -= p;
         b.hi[a] += p;
     }
@@ -627,6 +628,168 @@ class Reorder {
         return i + 1;
     }
 };
+
+// ---------------------------------------------------------------------------------------------- packed fast array
+// The form of the fast array the render kernels walk when the scene has no transform / medium brackets: 16-byte slots,
+//   box        half_boxes: 1 slot   6 halfs (centre x y z, half extent x y z), word 3 = first slot of the entry to jump
+//                                   to on a miss
+//              else:       2 slots  (centre.xyz as floats, miss link) (half extent.xyz as floats, 0)
+//   sphere     2 slots  (c0.xyz, tag) (dc.xyz, r)
+//   quad/tri   5 slots  (n.xyz, tag) (Q.xyz, d) (u.xyz, material) (v.xyz, prim id) (w.xyz, 0)
+//   end        1 slot   word 3 = ENT_END
+// tag = kind << 28 | index (kind >= 1), so a word 3 below PK_PRIM says "box" and is its miss link at the same time.
+// Centre / half-extent form needs no min / max per axis: the near and far plane distances are
+// centre_distance -+ half_extent * |1 / d|, three fused multiply-adds, which gfx950 issues at nearly twice the rate of
+// min / max / compare.  Arrays small enough for LDS keep float boxes (the walk is bound by vector issue there, and a
+// multiply-add that reads a half in place issues at the slow rate); larger arrays are walked from HBM / L2, where bytes
+// are what counts, and get half-precision boxes: one 16-byte read per box.  Rounding only loosens a box: the centre is
+// rounded to nearest and the half extent is rounded UP from what is needed to cover the given box around the rounded
+// centre; where a value does not fit a half (beyond 65504) the axis gets an infinite extent around 0 and never culls.
+constexpr uint32_t PK_PRIM = 0x10000000u;
+constexpr uint32_t PK_SLOT_BYTES = 16u;
+
+static inline uint16_t f16_nearest(float f) {  // IEEE binary16, round to nearest even; overflow -> inf, NaN -> NaN
+    uint32_t x = fbits(f);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // rounds to or beyond 65520 -> inf
+    if (x < 0x33000001u) return sign;                          // <= 2^-25 -> 0 (2^-25 itself ties to even = 0)
+    if (x < 0x38800000u) {                                     // result is a half denormal
+        const int shift = 126 - (int)(x >> 23);                // 14 .. 24
+        const uint32_t mant = (x & 0x7FFFFFu) | 0x800000u;
+        const uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t rem = x & 0x1FFFu;
+    uint32_t h = ((x - 0x38000000u) >> 13);
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+static inline float f16_value(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) {
+            x = sign;
+        } else {
+            float v = (float)m * (1.0f / 16777216.0f);  // m * 2^-24, exact
+            uint32_t b;
+            std::memcpy(&b, &v, 4);
+            x = sign | b;
+        }
+    } else if (e == 31) {
+        x = sign | 0x7F800000u | (m << 13);
+    } else {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
+static inline uint16_t f16_at_least(double v) {  // smallest non-negative half >= v (v >= 0)
+    uint16_t h = f16_nearest((float)v);
+    if (h >= 0x7C00u) return 0x7C00u;
+    if ((double)f16_value(h) < v) h++;  // next half up; 0x7BFF + 1 is +inf
+    return h;
+}
+
+struct Packed {
+    std::vector<uint32_t> words;  // 4 per slot
+    std::vector<uint32_t> rank;   // per slot: tie-break rank of the primitive whose entry starts there
+    std::vector<uint32_t> mat;    // per slot: material of that primitive, NONE elsewhere
+    size_t n_slots() const { return words.size() / 4; }
+};
+
+// planar: 5 x 4 floats per quad / triangle as the device keeps them ((Q,d) (u,mat) (v,0) (n,0) (w,0)), quads first, and
+// planar_id: their prim ids in the same order.  `t` is a fast array in entry-index form (before finalize).
+// Returns false when it holds brackets (or is too large for 28-bit slot links).
+static inline size_t packed_slots(const Threaded& t, bool half_boxes) {  // terminator included
+    size_t slots = 1;
+    for (const Ent& e : t.ents) {
+        const uint32_t kind = e.w[7] == ENT_BOX ? ENT_BOX : (e.w[7] & 15u);
+        slots += kind == ENT_BOX ? (half_boxes ? 1 : 2) : kind == ENT_SPHERE ? 2 : 5;
+    }
+    return slots;
+}
+
+static inline bool pack(const Threaded& t, const float* planar, const uint32_t* planar_id, uint32_t n_quads, bool half_boxes, Packed& out) {
+    if (t.has_brackets) return false;
+    const size_t n = t.ents.size();
+    std::vector<uint32_t> first(n + 1);
+    size_t slots = 0;
+    for (size_t i = 0; i < n; i++) {
+        first[i] = (uint32_t)slots;
+        const uint32_t w7 = t.ents[i].w[7];
+        const uint32_t kind = w7 == ENT_BOX ? ENT_BOX : (w7 & 15u);
+        slots += kind == ENT_BOX ? (half_boxes ? 1 : 2) : kind == ENT_SPHERE ? 2 : 5;
+    }
+    first[n] = (uint32_t)slots;
+    slots += 1;  // terminator
+    if (slots >= PK_PRIM) return false;
+    out.words.assign(4 * slots, 0u);
+    out.rank.assign(slots, 0u);
+    out.mat.assign(slots, NONE);
+    auto fval = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    for (size_t i = 0; i < n; i++) {
+        const Ent& e = t.ents[i];
+        uint32_t* w = &out.words[4 * (size_t)first[i]];
+        const uint32_t w7 = e.w[7];
+        if (w7 == ENT_BOX && !half_boxes) {
+            for (int a = 0; a < 3; a++) {
+                const float lo = fval(e.w[2 * a]), hi = fval(e.w[2 * a + 1]);
+                float c = 0.5f * lo + 0.5f * hi;
+                if (!std::isfinite(c)) c = 0.0f;
+                const double need = std::fmax((double)hi - (double)c, (double)c - (double)lo);
+                float h = (float)need;
+                if ((double)h < need) h = std::nextafter(h, std::numeric_limits<float>::infinity());
+                if (!(need == need)) h = std::numeric_limits<float>::infinity();  // NaN bounds: never cull
+                w[a] = fbits(c);
+                w[4 + a] = fbits(h);
+            }
+            w[3] = first[e.w[6]];
+            w[7] = 0;
+            continue;
+        }
+        if (w7 == ENT_BOX) {
+            uint16_t c[3], h[3];
+            for (int a = 0; a < 3; a++) {
+                const float lo = fval(e.w[2 * a]), hi = fval(e.w[2 * a + 1]);
+                c[a] = f16_nearest(0.5f * lo + 0.5f * hi);
+                const double cv = (double)f16_value(c[a]);
+                const double need = std::fmax((double)hi - cv, cv - (double)lo);
+                h[a] = f16_at_least(std::fmax(need, 0.0));
+                if ((c[a] & 0x7FFFu) >= 0x7C00u || !(need == need)) {  // centre does not fit a half (or NaN bounds): never cull on this axis
+                    c[a] = 0;
+                    h[a] = 0x7C00u;
+                }
+            }
+            w[0] = (uint32_t)c[0] | ((uint32_t)c[1] << 16);
+            w[1] = (uint32_t)c[2] | ((uint32_t)h[0] << 16);
+            w[2] = (uint32_t)h[1] | ((uint32_t)h[2] << 16);
+            w[3] = first[e.w[6]];  // e.w[6] <= n: the entry after the subtree, or the terminator
+            continue;
+        }
+        const uint32_t kind = w7 & 15u, index = w7 >> 4;
+        out.rank[first[i]] = t.rank[i];
+        out.mat[first[i]] = t.mat[i];
+        if (kind == ENT_SPHERE) {
+            w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2]; w[3] = (ENT_SPHERE << 28) | index;
+            w[4] = e.w[3]; w[5] = e.w[4]; w[6] = e.w[5]; w[7] = e.w[6];
+        } else {
+            const size_t p = kind == ENT_TRI ? (size_t)index + n_quads : index;
+            const float* r = planar + 20 * p;  // (Q,d) (u,mat) (v,0) (n,0) (w,0)
+            auto put3 = [&](uint32_t* dst, const float* src) { std::memcpy(dst, src, 12); };
+            put3(w + 0, r + 12);  w[3] = (kind << 28) | index;                     // n, tag
+            put3(w + 4, r + 0);   std::memcpy(w + 7, r + 3, 4);                    // Q, d
+            put3(w + 8, r + 4);   std::memcpy(w + 11, r + 7, 4);                   // u, material
+            put3(w + 12, r + 8);  w[15] = planar_id[p];             // v, prim id
+            put3(w + 16, r + 16); w[19] = 0;                                       // w
+        }
+    }
+    out.words[4 * (size_t)first[n] + 3] = ENT_END;
+    return true;
+}
 
 // Turn entry indices into byte offsets and append the terminator.
 static inline void finalize(Threaded& t) {

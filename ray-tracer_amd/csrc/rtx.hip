@@ -42,8 +42,44 @@ static int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Tuning knobs, read from the environment once per process.
+struct Knobs {
+    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, overlap, lds_ents_max, perlin_lds, waves_per_block,
+        blocks_per_cu, debug;
+};
+static const Knobs& knobs() {
+    static const Knobs k = [] {
+        auto u = [](const char* name, uint32_t dflt) {
+            const char* v = std::getenv(name);
+            return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
+        };
+        Knobs x;
+        x.view_order = u("RTX_VIEW_ORDER", 1);
+        x.items_per_wave = u("RTX_ITEMS_PER_WAVE", 0);
+        x.max_batches = u("RTX_MAX_BATCHES", 64);
+        x.sched_k = std::max(1u, u("RTX_SCHED_K", 4));
+        x.w_prim = std::max(1u, u("RTX_W_PRIM", 10));
+        x.w_serv = std::max(1u, u("RTX_W_SERV", 3));
+        x.sched_kp = u("RTX_SCHED_KP", 32);
+        x.overlap = u("RTX_OVERLAP", 1);
+        x.lds_ents_max = u("RTX_LDS_ENTS_MAX", 72 * 1024);
+        x.perlin_lds = u("RTX_PERLIN_LDS", 1);
+        x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
+        x.blocks_per_cu = u("RTX_BLOCKS_PER_CU", 0);
+        x.debug = u("RTX_DEBUG", 0);
+        return x;
+    }();
+    return k;
+}
+
 // ================================================================================================ scene
-constexpr size_t COUNTER_BYTES = 256;  // [0] item counter (u32); u64 words from byte 8: rays, box tests, primitive tests, then diagnostics
+constexpr size_t COUNTER_BYTES = 256;
+constexpr size_t PK_SHADE_TABLE_MAX_BYTES = 160 * 1024;  // packed arrays up to this size (any that can live in LDS) get a per-slot shading table
+
+static bool env_flag(const char* name, bool dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) != 0 : dflt;
+}  // [0] item counter (u32); u64 words from byte 8: rays, box tests, primitive tests, then diagnostics
 
 // The scene's device data on one GPU, with the render scratch that goes with it.
 struct DeviceCopy {
@@ -82,6 +118,13 @@ struct rtx_scene {
     // the fast array in entry-index form: re-ordered for a viewpoint when a render asks for it
     std::vector<uint4> mat_recs;  // 2 per material: the shading record a hit entry gets (see DevScene::shade)
     rtx_accel::Threaded fast_indexed;
+    // packed form of the fast array (bracket-free scenes): what re-packing for a viewpoint needs on the host
+    bool packed = false;
+    bool pk_half = false;  // boxes of the packed array in half precision (arrays too large for LDS)
+    uint32_t pk_slots = 0;
+    uint32_t n_quads = 0;
+    std::vector<float4> planar_host;      // 5 per quad / triangle, as uploaded
+    std::vector<uint32_t> planar_id_host;
 };
 
 template <class T>
@@ -197,10 +240,49 @@ extern "C" void rtx_scene_destroy(rtx_scene_t* s) {
     delete s;
 }
 
+// Planar records as the device keeps them, 5 x float4 per primitive -- (Q.xyz, d) (u.xyz, material bits) (v.xyz, 0)
+// (n.xyz, 0) (w.xyz, 0) -- quads first, then triangles, and their prim ids in the same order.
+static void build_planar(const rtx_scene_desc_t& desc, std::vector<float4>& planar, std::vector<uint32_t>& planar_id) {
+    const rtx_scene_desc_t* d = &desc;
+    auto bf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    // planar records: quads as given; triangles through the same derivation Quad::new applies to (Q, u, v)
+    // (mesh.rs:233-244) with Q = v0, u = v1 - v0, v = v2 - v0.
+    size_t n_planar = (size_t)d->n_quads + d->n_tris;
+    planar.assign(5 * n_planar, make_float4(0, 0, 0, 0));
+    planar_id.assign(n_planar, 0u);
+    for (uint32_t i = 0; i < d->n_quads; i++) {
+        const float* const* q = d->quad_f;
+        planar[5 * i + 0] = make_float4(q[0][i], q[1][i], q[2][i], q[15][i]);
+        planar[5 * i + 1] = make_float4(q[3][i], q[4][i], q[5][i], bf(d->quad_material[i]));
+        planar[5 * i + 2] = make_float4(q[6][i], q[7][i], q[8][i], 0.0f);
+        planar[5 * i + 3] = make_float4(q[9][i], q[10][i], q[11][i], 0.0f);
+        planar[5 * i + 4] = make_float4(q[12][i], q[13][i], q[14][i], 0.0f);
+        planar_id[i] = d->quad_prim_id[i];
+    }
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        const float* const* t = d->tri_f;
+        float q[3] = {t[0][i], t[1][i], t[2][i]};
+        float u[3] = {t[3][i] - q[0], t[4][i] - q[1], t[5][i] - q[2]};
+        float v[3] = {t[6][i] - q[0], t[7][i] - q[1], t[8][i] - q[2]};
+        float n[3] = {u[1] * v[2] - v[1] * u[2], u[2] * v[0] - v[2] * u[0], u[0] * v[1] - v[0] * u[1]};
+        float nn = (n[0] * n[0]) + (n[1] * n[1]) + (n[2] * n[2]);
+        float inv = 1.0f / std::sqrt(nn);
+        float nrm[3] = {n[0] * inv, n[1] * inv, n[2] * inv};
+        float dd = (nrm[0] * q[0]) + (nrm[1] * q[1]) + (nrm[2] * q[2]);
+        size_t p = (size_t)d->n_quads + i;
+        planar[5 * p + 0] = make_float4(q[0], q[1], q[2], dd);
+        planar[5 * p + 1] = make_float4(u[0], u[1], u[2], bf(d->tri_material[i]));
+        planar[5 * p + 2] = make_float4(v[0], v[1], v[2], 0.0f);
+        planar[5 * p + 3] = make_float4(nrm[0], nrm[1], nrm[2], 0.0f);
+        planar[5 * p + 4] = make_float4(n[0] / nn, n[1] / nn, n[2] / nn, 0.0f);
+        planar_id[p] = d->tri_prim_id[i];
+    }
+}
+
 extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal, const float* view, float grow, uint32_t* entries_out,
                                   uint32_t* rank_out, size_t capacity, size_t* n_entries) {
     if (!n_entries) return fail(RTX_ERR_INVALID, "null argument");
-    if (traversal > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    if (traversal > RTX_TRAVERSAL_FAST_FUSED) return fail(RTX_ERR_INVALID, "unknown traversal mode");
     int rc = validate(d);
     if (rc != RTX_OK) return rc;
     rtx_accel::Threaded strict, fast, indexed;
@@ -208,6 +290,25 @@ extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal,
     float range = 0.0f;
     rc = rtx_accel::build(*d, strict, fast, indexed, range, err);
     if (rc != RTX_OK) return fail(rc, err);
+    if (traversal == RTX_TRAVERSAL_FAST_FUSED) {
+        // the packed form: 4 words per 16-byte slot, rank per slot
+        const float origin[3] = {0.0f, 0.0f, 0.0f};
+        rtx_accel::Threaded ordered;
+        rtx_accel::Reorder(indexed, ordered).run(view ? view : origin, grow, view != nullptr);
+        std::vector<float4> planar;
+        std::vector<uint32_t> planar_id;
+        build_planar(*d, planar, planar_id);
+        rtx_accel::Packed pk;
+        const bool half = rtx_accel::packed_slots(ordered, false) * 16 > knobs().lds_ents_max || env_flag("RTX_PACKED_HALF", false);
+        if (!rtx_accel::pack(ordered, reinterpret_cast<const float*>(planar.data()), planar_id.data(), d->n_quads, half, pk))
+            return fail(RTX_ERR_UNSUPPORTED, "scenes with Translate / RotateY / ConstantMedium have no packed fast array");
+        *n_entries = pk.n_slots();
+        if (!entries_out) return RTX_OK;
+        if (capacity < pk.n_slots()) return fail(RTX_ERR_INVALID, "capacity too small");
+        std::memcpy(entries_out, pk.words.data(), pk.words.size() * 4);
+        if (rank_out) std::memcpy(rank_out, pk.rank.data(), pk.rank.size() * 4);
+        return RTX_OK;
+    }
     if (traversal == RTX_TRAVERSAL_FAST && (view || grow > 0.0f)) {
         const float origin[3] = {0.0f, 0.0f, 0.0f};
         rtx_accel::Threaded ordered;
@@ -229,6 +330,19 @@ static std::vector<uint4> expand_shade(const rtx_accel::Threaded& t, const std::
     std::vector<uint4> out(2 * t.ents.size(), make_uint4(0, 0, 0, 0));
     for (size_t i = 0; i < t.ents.size(); i++) {
         const uint32_t m = t.mat[i];
+        if (m != rtx_accel::NONE && 2 * (size_t)m + 1 < mat_recs.size()) {
+            out[2 * i] = mat_recs[2 * m];
+            out[2 * i + 1] = mat_recs[2 * m + 1];
+        }
+    }
+    return out;
+}
+
+// The same per slot of a packed array.
+static std::vector<uint4> expand_shade_packed(const rtx_accel::Packed& pk, const std::vector<uint4>& mat_recs) {
+    std::vector<uint4> out(2 * pk.n_slots(), make_uint4(0, 0, 0, 0));
+    for (size_t i = 0; i < pk.n_slots(); i++) {
+        const uint32_t m = pk.mat[i];
         if (m != rtx_accel::NONE && 2 * (size_t)m + 1 < mat_recs.size()) {
             out[2 * i] = mat_recs[2 * m];
             out[2 * i + 1] = mat_recs[2 * m + 1];
@@ -299,41 +413,36 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     if ((rc = upload(dc, sph, &dc->dev.sph)) != RTX_OK) return rc;
     if ((rc = upload(dc, sph_id, &dc->dev.sph_id)) != RTX_OK) return rc;
 
-    // planar records: quads as given; triangles through the same derivation Quad::new applies to (Q, u, v)
-    // (mesh.rs:233-244) with Q = v0, u = v1 - v0, v = v2 - v0.
-    size_t n_planar = (size_t)d->n_quads + d->n_tris;
-    std::vector<float4> planar(5 * n_planar);
-    std::vector<uint32_t> planar_id(n_planar);
-    for (uint32_t i = 0; i < d->n_quads; i++) {
-        const float* const* q = d->quad_f;
-        planar[5 * i + 0] = make_float4(q[0][i], q[1][i], q[2][i], q[15][i]);
-        planar[5 * i + 1] = make_float4(q[3][i], q[4][i], q[5][i], bf(d->quad_material[i]));
-        planar[5 * i + 2] = make_float4(q[6][i], q[7][i], q[8][i], 0.0f);
-        planar[5 * i + 3] = make_float4(q[9][i], q[10][i], q[11][i], 0.0f);
-        planar[5 * i + 4] = make_float4(q[12][i], q[13][i], q[14][i], 0.0f);
-        planar_id[i] = d->quad_prim_id[i];
-    }
-    for (uint32_t i = 0; i < d->n_tris; i++) {
-        const float* const* t = d->tri_f;
-        float q[3] = {t[0][i], t[1][i], t[2][i]};
-        float u[3] = {t[3][i] - q[0], t[4][i] - q[1], t[5][i] - q[2]};
-        float v[3] = {t[6][i] - q[0], t[7][i] - q[1], t[8][i] - q[2]};
-        float n[3] = {u[1] * v[2] - v[1] * u[2], u[2] * v[0] - v[2] * u[0], u[0] * v[1] - v[0] * u[1]};
-        float nn = (n[0] * n[0]) + (n[1] * n[1]) + (n[2] * n[2]);
-        float inv = 1.0f / std::sqrt(nn);
-        float nrm[3] = {n[0] * inv, n[1] * inv, n[2] * inv};
-        float dd = (nrm[0] * q[0]) + (nrm[1] * q[1]) + (nrm[2] * q[2]);
-        size_t p = (size_t)d->n_quads + i;
-        planar[5 * p + 0] = make_float4(q[0], q[1], q[2], dd);
-        planar[5 * p + 1] = make_float4(u[0], u[1], u[2], bf(d->tri_material[i]));
-        planar[5 * p + 2] = make_float4(v[0], v[1], v[2], 0.0f);
-        planar[5 * p + 3] = make_float4(nrm[0], nrm[1], nrm[2], 0.0f);
-        planar[5 * p + 4] = make_float4(n[0] / nn, n[1] / nn, n[2] / nn, 0.0f);
-        planar_id[p] = d->tri_prim_id[i];
-    }
+    std::vector<float4> planar;
+    std::vector<uint32_t> planar_id;
+    build_planar(*d, planar, planar_id);
     if ((rc = upload(dc, planar, &dc->dev.planar)) != RTX_OK) return rc;
     if ((rc = upload(dc, planar_id, &dc->dev.planar_id)) != RTX_OK) return rc;
     dc->dev.n_quads = d->n_quads;
+    s->n_quads = d->n_quads;
+    if ((rc = upload(dc, s->mat_recs, &dc->dev.mat_recs)) != RTX_OK) return rc;
+    {
+        // the packed form of the fast array, which the render kernels walk when the scene has no brackets
+        rtx_accel::Packed pk;
+        s->pk_half = rtx_accel::packed_slots(s->fast_indexed, false) * 16 > knobs().lds_ents_max || env_flag("RTX_PACKED_HALF", false);
+        s->packed = env_flag("RTX_PACKED", true) &&
+                    rtx_accel::pack(s->fast_indexed, reinterpret_cast<const float*>(planar.data()), planar_id.data(), d->n_quads, s->pk_half, pk);
+        if (s->packed) {
+            const uint4* words = nullptr;
+            std::vector<uint4> w4(pk.n_slots());
+            std::memcpy(w4.data(), pk.words.data(), pk.words.size() * 4);
+            if ((rc = upload(dc, w4, &words)) != RTX_OK) return rc;
+            dc->dev.pk = words;
+            dc->dev.pk_slots = s->pk_slots = (uint32_t)pk.n_slots();
+            dc->dev.pk_half = s->pk_half ? 1u : 0u;
+            if ((rc = upload(dc, pk.rank, &dc->dev.pk_rank)) != RTX_OK) return rc;
+            if (pk.n_slots() * 16 <= PK_SHADE_TABLE_MAX_BYTES) {
+                if ((rc = upload(dc, expand_shade_packed(pk, s->mat_recs), &dc->dev.pk_shade)) != RTX_OK) return rc;
+            }
+            s->planar_host = planar;
+            s->planar_id_host = planar_id;
+        }
+    }
 
     std::vector<uint4> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; i++) {
@@ -465,6 +574,49 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
     hits[i] = out;
 }
 
+// The same contract over the packed form of the fast array, with the box test the render kernels use.
+__global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
+                                                            rtx_hit_t* __restrict__ hits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SlotReader slots{S.pk};
+    const uint32_t* __restrict__ rank = S.pk_rank;
+    Ray r;
+    r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
+    r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
+    r.time = rays[i].time;
+    const RayConst rc = ray_const<SLAB_FMA>(r);
+    Best best;
+    best.t = tmax;
+    best.ent = NO_HIT;
+    uint32_t off = 0;
+    for (;;) {
+        const uint4 e = slots.at(off);
+        if (e.w == ENT_END) break;
+        if (e.w < PK_PRIM) {
+            const bool hit = S.pk_half ? pk_slab_hit(e, rc, tmin, best.t) : pk_slab_hit(e, slots.at(off + PK_SLOT), rc, tmin, best.t);
+            off = hit ? off + (S.pk_half ? PK_SLOT : 2u * PK_SLOT) : e.w * PK_SLOT;
+        } else {
+            const uint32_t at = off;
+            off += pk_prim_test(e, slots.at(off + PK_SLOT), [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); }, off, r, rc, tmin, best, rank);
+        }
+    }
+    rtx_hit_t out;
+    std::memset(&out, 0, sizeof(out));
+    out.prim_id = RTX_MISS;
+    if (best.ent != NO_HIT) {
+        const uint32_t at = best.ent;
+        HitRec h = pk_make_hit<true, true, true>(S, [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); }, r, best.t);
+        out.prim_id = h.prim_id;
+        out.t = best.t;
+        out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
+        out.uv[0] = h.u; out.uv[1] = h.v;
+        out.front_face = 1;  // Hit::new stores `front_face: true` unconditionally (mesh.rs:47)
+        out.p[0] = h.px; out.p[1] = h.py; out.p[2] = h.pz;
+    }
+    hits[i] = out;
+}
+
 extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
                                 void* stream) {
     if (!scene || !opts || (n && (!rays_dev || !hits_dev))) return fail(RTX_ERR_INVALID, "null argument");
@@ -478,6 +630,8 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
         hipLaunchKernelGGL((trace_kernel<true, SLAB_STRICT>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST)
         hipLaunchKernelGGL((trace_kernel<false, SLAB_ROBUST>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+    else if (scene->packed)  // what the render kernels walk for this scene
+        hipLaunchKernelGGL(trace_packed_kernel, grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else
         hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     HIP_TRY(hipGetLastError());
@@ -549,17 +703,23 @@ extern __shared__ uint4 smem[];
 // fullest -- box tests, primitive tests, or service (shade + scatter, then ray generation for the lanes that became
 // free) -- for exactly the lanes queued for it.  Lanes are never moved: compaction happens in time, by always running
 // the stage most lanes wait for.
-template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX>
+// PK: walk the packed form of the fast array (16-byte slots, half-precision boxes) instead of the 32-byte entries; only
+// for the fast walk of scenes without brackets (!STRICT && !XF).
+template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false>
 __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_kernel(RenderParams P) {
+    static_assert(!PK || (!STRICT && !XF), "the packed array exists for the fast walk of bracket-free scenes only");
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
     const DevScene& S = P.S;
-    const uint4* __restrict__ gents = S.ents[M];
-    const uint32_t* __restrict__ rank = S.rank[M];
+    const uint4* __restrict__ gents = PK ? S.pk : S.ents[M];
+    const uint32_t* __restrict__ rank = PK ? S.pk_rank : S.rank[M];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // what word 3 / word 7 of the entry a lane stands at says about the lane
+    auto at_box = [](uint32_t w) { return PK ? w < PK_PRIM : w == ENT_BOX; };
+    auto at_prim = [](uint32_t w) { return PK ? w - PK_PRIM < ENT_END - PK_PRIM : w - 1u < ENT_END - 1u; };
 
     // LDS: [entries incl. terminator (optional)] [per-wave tile accumulators]
-    const uint32_t ent_u4 = ENTS_IN_LDS ? 2u * S.n_ents[M] : 0u;
+    const uint32_t ent_u4 = ENTS_IN_LDS ? (PK ? S.pk_slots : 2u * S.n_ents[M]) : 0u;
     float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * (2 * ACC_FLOATS);
     if (ENTS_IN_LDS) {
         for (uint32_t i = threadIdx.x; i < ent_u4; i += blockDim.x) smem[i] = gents[i];
@@ -623,14 +783,32 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
             b = *reinterpret_cast<const uint4*>(base_ + 16);                   \
         }                                                                      \
     } while (0)
-#define RTX_LOAD_STATE(o, w)                                                                          \
-    do {                                                                                             \
-        if (ENTS_IN_LDS) {                                                                           \
-            w = *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(uint32_t)((o) + 28u); \
-        } else {                                                                                     \
-            w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(gents) + (o) + 28u); \
-        }                                                                                            \
+#define RTX_LOAD_SLOT(o, a)                                                                    \
+    do {                                                                                       \
+        if (ENTS_IN_LDS) {                                                                     \
+            const u32x4 a_ = *(lds_u4*)(uintptr_t)(uint32_t)(o);                               \
+            a = make_uint4(a_.x, a_.y, a_.z, a_.w);                                            \
+        } else {                                                                               \
+            a = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(gents) + (o));   \
+        }                                                                                      \
     } while (0)
+    constexpr uint32_t STATE_AT = PK ? 12u : 28u;  // byte offset of the state word in an entry
+#define RTX_LOAD_STATE(o, w)                                                                              \
+    do {                                                                                                 \
+        if (ENTS_IN_LDS) {                                                                               \
+            w = *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)(uint32_t)((o) + STATE_AT); \
+        } else {                                                                                         \
+            w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(gents) + (o) + STATE_AT); \
+        }                                                                                                \
+    } while (0)
+    // reads slot k of the packed entry at byte offset o (shading, rare paths)
+    auto slot_of = [&](uint32_t o) {
+        return [=](int k) {
+            uint4 v;
+            RTX_LOAD_SLOT(o + (uint32_t)k * PK_SLOT, v);
+            return v;
+        };
+    };
     uint32_t root_st;  // queue of the first entry (wave-uniform)
     RTX_LOAD_STATE(0u, root_st);
     root_st = __builtin_amdgcn_readfirstlane(root_st);
@@ -682,7 +860,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     RTX_CLAIM(A, a_sel);
     if (A.pool_total != 0u) {
         for (;;) {
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(st == ENT_BOX));
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(at_box(st)));
             const uint32_t n_done = (uint32_t)__popcll(__ballot(st == ENT_END));
             const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
             const uint32_t n_prim = 64u - n_box - n_done - n_idle;
@@ -731,25 +909,53 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 // ---- extend, box stage: Aabb::hit for the lanes standing at a box; keep going while boxes stay the
                 //      largest queue (one ballot per step: everything that is not BOX is "the rest")
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
-                uint32_t nb;
+                uint32_t nb = n_box;
                 RTX_TIC();
-                uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
-                if (st == ENT_BOX) RTX_LOAD_ENTRY(off, ea, eb);
-                nb = n_box;
-                do {
-                    wave_box += nb;
-#ifdef RTX_STAGE_COUNTERS
-                    sc[0]++;
-                    sc[1] += __popcll(__ballot(st == ENT_BOX));
-#endif
-                    if (st == ENT_BOX) {
-                        const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, XF ? wx.tmin : tmin, best.t);
-                        off = hit ? off + ENT_BYTES : eb.z;
-                        RTX_LOAD_ENTRY(off, ea, eb);
-                        st = eb.w;
+                if (PK) {
+                    // The lane's state word is the box's miss link (in slots).  Arrays in LDS keep float boxes (two slots),
+                    // arrays in HBM half-precision ones (one slot).
+                    constexpr uint32_t BOX_BYTES = ENTS_IN_LDS ? 2u * PK_SLOT : PK_SLOT;
+                    const uint32_t k1 = P.sched_k + 1u;
+                    bool here = at_box(st);
+                    uint4 e = make_uint4(0, 0, 0, 0), e1 = e;
+                    if (here) {
+                        RTX_LOAD_SLOT(off, e);
+                        if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
                     }
-                    nb = (uint32_t)__popcll(__ballot(st == ENT_BOX));
-                } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
+                    do {
+                        wave_box += nb;
+#ifdef RTX_STAGE_COUNTERS
+                        sc[0]++;
+                        sc[1] += nb;
+#endif
+                        if (here) {
+                            const bool hit = ENTS_IN_LDS ? pk_slab_hit(e, e1, rc, tmin, best.t) : pk_slab_hit(e, rc, tmin, best.t);
+                            off = hit ? off + BOX_BYTES : st * PK_SLOT;
+                            RTX_LOAD_SLOT(off, e);
+                            if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
+                            st = e.w;
+                        }
+                        here = at_box(st);
+                        nb = (uint32_t)__popcll(__ballot(here));
+                    } while (nb * k1 >= n_fixed && nb > 0);
+                } else {
+                    uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
+                    if (st == ENT_BOX) RTX_LOAD_ENTRY(off, ea, eb);
+                    do {
+                        wave_box += nb;
+#ifdef RTX_STAGE_COUNTERS
+                        sc[0]++;
+                        sc[1] += __popcll(__ballot(st == ENT_BOX));
+#endif
+                        if (st == ENT_BOX) {
+                            const bool hit = slab_hit<SLAB>(ea, eb, ray, rc, XF ? wx.tmin : tmin, best.t);
+                            off = hit ? off + ENT_BYTES : eb.z;
+                            RTX_LOAD_ENTRY(off, ea, eb);
+                            st = eb.w;
+                        }
+                        nb = (uint32_t)__popcll(__ballot(st == ENT_BOX));
+                    } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
+                }
                 RTX_TOC(0);
             } else if (n_prim != 0u && (sc_prim >= sc_serv || n_serv == 0u)) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive; repeated
@@ -761,9 +967,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                     wave_prim += np;
 #ifdef RTX_STAGE_COUNTERS
                     sc[2]++;
-                    sc[3] += __popcll(__ballot(st - 1u < ENT_END - 1u));
+                    sc[3] += np;
 #endif
-                    if (st - 1u < ENT_END - 1u) {  // neither box (0) nor done / idle
+                    if (PK) {
+                        if (at_prim(st)) {
+                            uint4 s0, s1;
+                            RTX_LOAD_SLOT(off, s0);
+                            RTX_LOAD_SLOT(off + PK_SLOT, s1);
+                            off += pk_prim_test(s0, s1, slot_of(off), off, ray, rc, tmin, best, rank);
+                            RTX_LOAD_STATE(off, st);
+                        }
+                    } else if (at_prim(st)) {  // neither box (0) nor done / idle
                         uint4 ea, eb;
                         RTX_LOAD_ENTRY(off, ea, eb);
                         const uint32_t kind = eb.w & 15u;
@@ -784,7 +998,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         }
                         RTX_LOAD_STATE(off, st);
                     }
-                    np = (uint32_t)__popcll(__ballot(st - 1u < ENT_END - 1u));
+                    np = (uint32_t)__popcll(__ballot(at_prim(st)));
                 } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // in the lean variant the loop would cost registers, i.e. a resident wave
                 RTX_TOC(1);
             } else {
@@ -804,13 +1018,31 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         atomicAdd(&acc[slot * 3 + 2], bb * C.background[2]);
                     } else {
                         HitRec h;
-                        // what the hit is shaded with: one read, indexed like the entries (issued first: it is the long one)
-                        const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.shade[M]) + best.ent);
-                        const uint4 s0 = srec[0], s1 = srec[1];
-                        {
+                        uint4 s0, s1;  // what the hit is shaded with (layout: DevScene::shade)
+                        if (PK) {
+                            const auto slots = slot_of(best.ent);
+                            if (ENTS_IN_LDS) {
+                                // one read, indexed like the slots (issued first: it is the long one)
+                                const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.pk_shade) + 2u * best.ent);
+                                s0 = srec[0];
+                                s1 = srec[1];
+                            } else {
+                                // large scenes keep no per-slot table: the entry names its material (a sphere through its record)
+                                const uint4 first = slots(0);
+                                const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(S.sph[2u * (first.w & (PK_PRIM - 1u)) + 1u].w) : slots(2).w;
+                                s0 = S.mat_recs[2u * m];
+                                s1 = S.mat_recs[2u * m + 1u];
+                            }
+                            // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
+                            const bool want_uv = TEX && (s0.x & 512u) != 0u;
+                            h = want_uv ? pk_make_hit<true, false, false>(S, slots, ray, best.t) : pk_make_hit<false, false, false>(S, slots, ray, best.t);
+                        } else {
+                            // one read, indexed like the entries (issued first: it is the long one)
+                            const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.shade[M]) + best.ent);
+                            s0 = srec[0];
+                            s1 = srec[1];
                             uint4 ha, hb;
                             RTX_LOAD_ENTRY(best.ent, ha, hb);
-                            // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
                             if (XF) {
                                 h = want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
@@ -918,6 +1150,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     }
 #undef RTX_CLAIM
 #undef RTX_LOAD_ENTRY
+#undef RTX_LOAD_SLOT
 #undef RTX_LOAD_STATE
 #undef RTX_BEGIN_WALK
     // one ray-count update per wave
@@ -969,39 +1202,9 @@ static int check_camera(const rtx_camera_t* c) {
     return RTX_OK;
 }
 
-// Tuning knobs, read from the environment once per process.
-struct Knobs {
-    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, overlap, lds_ents_max, perlin_lds, waves_per_block,
-        blocks_per_cu, debug;
-};
-static const Knobs& knobs() {
-    static const Knobs k = [] {
-        auto u = [](const char* name, uint32_t dflt) {
-            const char* v = std::getenv(name);
-            return v ? (uint32_t)std::strtoul(v, nullptr, 10) : dflt;
-        };
-        Knobs x;
-        x.view_order = u("RTX_VIEW_ORDER", 1);
-        x.items_per_wave = u("RTX_ITEMS_PER_WAVE", 0);
-        x.max_batches = u("RTX_MAX_BATCHES", 64);
-        x.sched_k = std::max(1u, u("RTX_SCHED_K", 4));
-        x.w_prim = std::max(1u, u("RTX_W_PRIM", 10));
-        x.w_serv = std::max(1u, u("RTX_W_SERV", 3));
-        x.sched_kp = u("RTX_SCHED_KP", 32);
-        x.overlap = u("RTX_OVERLAP", 1);
-        x.lds_ents_max = u("RTX_LDS_ENTS_MAX", 72 * 1024);
-        x.perlin_lds = u("RTX_PERLIN_LDS", 1);
-        x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
-        x.blocks_per_cu = u("RTX_BLOCKS_PER_CU", 0);
-        x.debug = u("RTX_DEBUG", 0);
-        return x;
-    }();
-    return k;
-}
-
 // What a camera needs from the fast array: the viewpoint it should be ordered for and how far its boxes must be grown.
 // `reach` is the largest |coordinate| a camera ray can start from; beyond the range the boxes were padded for, they are
-// enlarged by the rounding error of the fused box test at that distance (~1.2e-7 * |origin| per plane, taken 4x).
+// enlarged by the rounding error of the fused box tests at that distance (~2.4e-7 * |origin| per plane, taken 3x).
 struct ViewNeed {
     bool strict_only;  // no finite reach: only the strict walk is safe
     float grow;
@@ -1013,7 +1216,7 @@ static ViewNeed view_need(const rtx_scene* scene, const rtx_camera_t* cam) {
     const float reach = cmax + 2.0f * dmax;
     ViewNeed n;
     n.strict_only = !std::isfinite(reach) || reach > 1e12f;
-    n.grow = (!n.strict_only && reach > scene->coord_range) ? 4.5e-7f * reach : 0.0f;
+    n.grow = (!n.strict_only && reach > scene->coord_range) ? 7e-7f * reach : 0.0f;
     return n;
 }
 
@@ -1023,9 +1226,23 @@ static int order_fast_for_view(rtx_scene* scene, DeviceCopy* c, const float cent
     if (c->view_valid && std::memcmp(c->view, center, sizeof(c->view)) == 0 && grow == c->view_grow) return RTX_OK;
     rtx_accel::Threaded ordered;
     rtx_accel::Reorder(scene->fast_indexed, ordered).run(center, grow);
+    rtx_accel::Packed pk;
+    if (scene->packed) {
+        if (!rtx_accel::pack(ordered, reinterpret_cast<const float*>(scene->planar_host.data()), scene->planar_id_host.data(), scene->n_quads, scene->pk_half, pk) ||
+            pk.n_slots() != scene->pk_slots)
+            return fail(RTX_ERR_DEVICE, "internal: re-ordered packed array changed size");
+    }
     rtx_accel::finalize(ordered);
     if (ordered.ents.size() != scene->n_ents[RTX_TRAVERSAL_FAST]) return fail(RTX_ERR_DEVICE, "internal: re-ordered array changed size");
     HIP_TRY(hipDeviceSynchronize());  // no walk may be in flight while the array is replaced
+    if (scene->packed) {
+        HIP_TRY(hipMemcpy(const_cast<uint4*>(c->dev.pk), pk.words.data(), pk.words.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(const_cast<uint32_t*>(c->dev.pk_rank), pk.rank.data(), pk.rank.size() * 4, hipMemcpyHostToDevice));
+        if (c->dev.pk_shade) {
+            const std::vector<uint4> sh = expand_shade_packed(pk, scene->mat_recs);
+            HIP_TRY(hipMemcpy(const_cast<uint4*>(c->dev.pk_shade), sh.data(), sh.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        }
+    }
     HIP_TRY(hipMemcpy(const_cast<uint4*>(c->dev.ents[RTX_TRAVERSAL_FAST]), ordered.ents.data(), ordered.ents.size() * sizeof(rtx_accel::Ent), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(const_cast<uint32_t*>(c->dev.rank[RTX_TRAVERSAL_FAST]), ordered.rank.data(), ordered.rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     const std::vector<uint4> shade = expand_shade(ordered, scene->mat_recs);
@@ -1140,7 +1357,8 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     P.ray_counter = reinterpret_cast<unsigned long long*>(scratch->counters + 2);
     HIP_TRY(hipMemsetAsync(scratch->counters, 0, COUNTER_BYTES, st));
 
-    const size_t ent_bytes = (size_t)scene->n_ents[M] * 32;
+    const bool pk = M == RTX_TRAVERSAL_FAST && scene->packed;  // (a scene with brackets has no packed array)
+    const size_t ent_bytes = pk ? (size_t)scene->pk_slots * 16 : (size_t)scene->n_ents[M] * 32;
     const bool in_lds = ent_bytes <= K.lds_ents_max;
     // one instantiation per (traversal, entries in LDS, brackets, uv / noise textures): features a scene does not use
     // cost registers, and registers cost resident waves
@@ -1151,7 +1369,11 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         render_kernel<true, false, false, true>,   render_kernel<true, false, true, false>,  render_kernel<true, false, true, true>,
         render_kernel<true, true, false, false>,   render_kernel<true, true, false, true>,   render_kernel<true, true, true, false>,
         render_kernel<true, true, true, true>};
-    void (*kern)(RenderParams) = kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
+    static void (*const packed_kernels[4])(RenderParams) = {
+        render_kernel<false, false, false, false, true>, render_kernel<false, false, false, true, true>,
+        render_kernel<false, true, false, false, true>,  render_kernel<false, true, false, true, true>};
+    void (*kern)(RenderParams) = pk ? packed_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
+                                    : kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
     // noise textures read their tables 336 times per value: table set 0 goes to LDS (6 KB per block)
     const size_t perlin_lds = scene->has_tex && scene->n_perlins != 0 && K.perlin_lds != 0u ? 1536 * sizeof(float) : 0;
@@ -1369,6 +1591,12 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
     RTX_REBASE(texs);
     RTX_REBASE(images);
     RTX_REBASE(perlin);
+    RTX_REBASE(mat_recs);
+    if (p.dev.pk) {
+        RTX_REBASE(pk);
+        RTX_REBASE(pk_rank);
+        if (p.dev.pk_shade) RTX_REBASE(pk_shade);
+    }
 #undef RTX_REBASE
     if (scene->n_images != 0) {  // the image table itself holds device pointers
         std::vector<DevImage> im(scene->n_images);

@@ -43,6 +43,14 @@ struct DevScene {
     const uint4* texs;         // 2 per texture: (kind, scale bits, a, b) (r, g, b bits, 0)
     const DevImage* images;
     const float* perlin;       // per table set: 768 floats (values) + 3 * 256 uint32 (perm x, y, z)
+    // The packed form of the fast array (16-byte slots, half-precision boxes; see accel.hpp), null when the scene has
+    // transform / medium brackets.  The render kernels walk it instead of ents[RTX_TRAVERSAL_FAST].
+    const uint4* pk;
+    uint32_t pk_slots;         // terminator included
+    uint32_t pk_half;          // 1: boxes are one slot of halfs; 0: two slots of floats
+    const uint32_t* pk_rank;   // per slot: tie-break rank of the primitive whose entry starts there
+    const uint4* pk_shade;     // per slot, 2 x uint4 in the layout of `shade`; null when the array is too large for LDS
+    const uint4* mat_recs;     // 2 x uint4 per material: the record `shade` holds for an entry of that material
 };
 
 struct Ray {
@@ -206,16 +214,17 @@ struct Best {
 //  strict: Interval::contains (lib.rs:82-84) against the shrinking interval: tmin <= t < best.
 //  fast  : same closest hit, visited in another order: on an exact tie the primitive the reference tests
 //          first (lower rank) wins, as it does there because the later one needs t < tmax.
-template <bool STRICT>
+//  SHIFT : log2 of the bytes one rank-table element stands for (32-byte entries: 5; 16-byte slots of the packed array: 4).
+template <bool STRICT, int SHIFT = 5>
 __device__ __forceinline__ bool in_range(float t, float tmin, const Best& b, uint32_t off, const uint32_t* __restrict__ rank) {
     if (STRICT) return tmin <= t && t < b.t;
     if (!(tmin <= t)) return false;
     if (t < b.t) return true;
-    return t == b.t && b.ent != NO_HIT && rank[off / ENT_BYTES] < rank[b.ent / ENT_BYTES];
+    return t == b.t && b.ent != NO_HIT && rank[off >> SHIFT] < rank[b.ent >> SHIFT];
 }
 
 // Sphere::hit up to the accepted root (mesh.rs:113-133).
-template <bool STRICT>
+template <bool STRICT, int SHIFT = 5>
 __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, Best& best,
                                             uint32_t idx, const uint32_t* __restrict__ rank) {
     float cx = as_f(ea.x) + as_f(ea.w) * r.time;  // center(time) = initial_center + center_delta * time (mesh.rs:178-180)
@@ -230,29 +239,30 @@ __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, co
     float sqrtd = __builtin_sqrtf(disc);
     float root = (h - sqrtd) / rc.a;
     if (STRICT) {
-        if (!in_range<true>(root, tmin, best, idx, rank)) {
+        if (!in_range<true, SHIFT>(root, tmin, best, idx, rank)) {
             root = (h + sqrtd) / rc.a;
-            if (!in_range<true>(root, tmin, best, idx, rank)) return;
+            if (!in_range<true, SHIFT>(root, tmin, best, idx, rank)) return;
         }
     } else {
         // the first root inside [tmin, end) is the near one unless it lies before tmin
         if (!(tmin <= root)) root = (h + sqrtd) / rc.a;
-        if (!in_range<false>(root, tmin, best, idx, rank)) return;
+        if (!in_range<false, SHIFT>(root, tmin, best, idx, rank)) return;
     }
     best.t = root;
     best.ent = idx;
 }
 
 // Quad::hit (mesh.rs:202-221, :248-256); TRI uses the same plane / alpha / beta with the triangle's domain.
-template <bool STRICT>
-__device__ __forceinline__ void planar_test(const float4* __restrict__ planar, uint32_t pidx, bool is_tri, const Ray& r, float tmin, Best& best,
-                                            uint32_t idx, const uint32_t* __restrict__ rank) {
-    const float4 q = planar[5 * pidx], n = planar[5 * pidx + 3];
+// LD(k) returns record k of the primitive: 0 (Q.xyz, d)  1 (u.xyz, ..)  2 (v.xyz, ..)  3 (n.xyz, ..)  4 (w.xyz, ..).
+template <bool STRICT, int SHIFT, class LD>
+__device__ __forceinline__ void planar_test_ld(LD ld, bool is_tri, const Ray& r, float tmin, Best& best, uint32_t idx,
+                                               const uint32_t* __restrict__ rank) {
+    const float4 q = ld(0), n = ld(3);
     float denom = dot3(n.x, n.y, n.z, r.dx, r.dy, r.dz);
     if (fabsf(denom) < 1e-8f) return;
     float t = (q.w - dot3(n.x, n.y, n.z, r.ox, r.oy, r.oz)) / denom;
-    if (!in_range<STRICT>(t, tmin, best, idx, rank)) return;
-    const float4 u = planar[5 * pidx + 1], v = planar[5 * pidx + 2], w = planar[5 * pidx + 4];
+    if (!in_range<STRICT, SHIFT>(t, tmin, best, idx, rank)) return;
+    const float4 u = ld(1), v = ld(2), w = ld(4);
     float px = (r.ox + r.dx * t) - q.x, py = (r.oy + r.dy * t) - q.y, pz = (r.oz + r.dz * t) - q.z;
     // alpha = w . (p x v), beta = w . (u x p)   with glam's cross
     float alpha = dot3(w.x, w.y, w.z, py * v.z - v.y * pz, pz * v.x - v.z * px, px * v.y - v.x * py);
@@ -262,6 +272,11 @@ __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, u
     if (!inside) return;
     best.t = t;
     best.ent = idx;
+}
+template <bool STRICT>
+__device__ __forceinline__ void planar_test(const float4* __restrict__ planar, uint32_t pidx, bool is_tri, const Ray& r, float tmin, Best& best,
+                                            uint32_t idx, const uint32_t* __restrict__ rank) {
+    planar_test_ld<STRICT, 5>([&](int k) { return planar[5 * pidx + k]; }, is_tri, r, tmin, best, idx, rank);
 }
 
 // One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
@@ -341,6 +356,126 @@ __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, c
         h.prim_id = S.planar_id[p];
     }
     bool front = dot3(r.dx, r.dy, r.dz, nx, ny, nz) < 0.0f;  // mesh.rs:40
+    h.nx = front ? nx : -nx;
+    h.ny = front ? ny : -ny;
+    h.nz = front ? nz : -nz;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------- packed fast array
+// 16-byte slots (layout: accel.hpp).  Word 3 of an entry's first slot is the walk state of a lane standing there:
+// below PK_PRIM = box (and its miss link, in slots), kind << 28 | index = primitive, ENT_END = walk complete.
+constexpr uint32_t PK_PRIM = 0x10000000u;
+constexpr uint32_t PK_SLOT = 16u;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// Box test in centre / half-extent form: per axis the distance to the centre plane, minus / plus half_extent * |1 / d|
+// (three fused operations that read the halfs in place, no min / max).  Same conservative answer as slab_hit<SLAB_FMA>
+// on the float box the halfs were rounded outward from; the boxes' padding covers the extra rounding step.
+__device__ __forceinline__ bool pk_slab_hit(const uint4& e, const RayConst& rc, float tmin, float tmax) {
+    const half2_t a = __builtin_bit_cast(half2_t, e.x), b = __builtin_bit_cast(half2_t, e.y), c = __builtin_bit_cast(half2_t, e.z);
+    const float tcx = __builtin_fmaf((float)a.x, rc.ix, rc.nx);
+    const float tcy = __builtin_fmaf((float)a.y, rc.iy, rc.ny);
+    const float tcz = __builtin_fmaf((float)b.x, rc.iz, rc.nz);
+    const float hx = (float)b.y, hy = (float)c.x, hz = (float)c.y;
+    const float ax = __builtin_fabsf(rc.ix), ay = __builtin_fabsf(rc.iy), az = __builtin_fabsf(rc.iz);
+    const float enter = fmaxf(fmaxf(__builtin_fmaf(-hx, ax, tcx), __builtin_fmaf(-hy, ay, tcy)), fmaxf(__builtin_fmaf(-hz, az, tcz), tmin));
+    const float exit3 = fminf(fminf(__builtin_fmaf(hx, ax, tcx), __builtin_fmaf(hy, ay, tcy)), __builtin_fmaf(hz, az, tcz));
+    float exit;
+    asm("v_min_f32 %0, %1, %2" : "=v"(exit) : "v"(exit3), "v"(tmax));  // as in slab_hit: no re-quieting of the interval end
+    return !(exit <= enter);
+}
+
+// The same with float centre / half extent: s0 = (centre.xyz, link), s1 = (half extent.xyz, 0).
+__device__ __forceinline__ bool pk_slab_hit(const uint4& s0, const uint4& s1, const RayConst& rc, float tmin, float tmax) {
+    const float tcx = __builtin_fmaf(as_f(s0.x), rc.ix, rc.nx);
+    const float tcy = __builtin_fmaf(as_f(s0.y), rc.iy, rc.ny);
+    const float tcz = __builtin_fmaf(as_f(s0.z), rc.iz, rc.nz);
+    const float hx = as_f(s1.x), hy = as_f(s1.y), hz = as_f(s1.z);
+    const float ax = __builtin_fabsf(rc.ix), ay = __builtin_fabsf(rc.iy), az = __builtin_fabsf(rc.iz);
+    const float enter = fmaxf(fmaxf(__builtin_fmaf(-hx, ax, tcx), __builtin_fmaf(-hy, ay, tcy)), fmaxf(__builtin_fmaf(-hz, az, tcz), tmin));
+    const float exit3 = fminf(fminf(__builtin_fmaf(hx, ax, tcx), __builtin_fmaf(hy, ay, tcy)), __builtin_fmaf(hz, az, tcz));
+    float exit;
+    asm("v_min_f32 %0, %1, %2" : "=v"(exit) : "v"(exit3), "v"(tmax));
+    return !(exit <= enter);
+}
+
+// Reads slots of the packed array through a generic pointer (trace kernel, rare paths).
+struct SlotReader {
+    const uint4* base;
+    __device__ __forceinline__ uint4 at(uint32_t off) const { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + off); }
+};
+__device__ __forceinline__ float4 as_f4(const uint4& u) { return make_float4(as_f(u.x), as_f(u.y), as_f(u.z), as_f(u.w)); }
+
+// Primitive test at the packed entry whose first two slots are s0, s1 (byte offset off); LD(k) reads slot k of it.
+// Returns the entry's size in bytes.
+template <class LD>
+__device__ __forceinline__ uint32_t pk_prim_test(const uint4& s0, const uint4& s1, LD ld, uint32_t off, const Ray& r, const RayConst& rc, float tmin,
+                                                 Best& best, const uint32_t* __restrict__ rank) {
+    const uint32_t kind = s0.w >> 28;
+    if (kind == ENT_SPHERE) {
+        // slots (c0.xyz, tag) (dc.xyz, r) in the word order sphere_test reads an unpacked entry
+        sphere_test<false, 4>(make_uint4(s0.x, s0.y, s0.z, s1.x), make_uint4(s1.y, s1.z, s1.w, 0u), r, rc, tmin, best, off, rank);
+        return 2u * PK_SLOT;
+    }
+    // slots (n, tag) (Q, d) (u, material) (v, prim id) (w, 0) -> records 0 Q  1 u  2 v  3 n  4 w
+    planar_test_ld<false, 4>(
+        [&](int k) { return k == 0 ? as_f4(s1) : k == 3 ? as_f4(s0) : as_f4(ld(k == 4 ? 4 : k + 1)); }, kind == ENT_TRI, r, tmin, best, off, rank);
+    return 5u * PK_SLOT;
+}
+
+// Hit record of the packed entry at the accepted offset.  IDS: also fill material and prim id (one more read for a sphere).
+template <bool WANT_UV, bool EXACT, bool IDS, class LD>
+__device__ __forceinline__ HitRec pk_make_hit(const DevScene& S, LD ld, const Ray& r, float t) {
+    const uint4 s0 = ld(0), s1 = ld(1);
+    const uint32_t kind = s0.w >> 28, pi = s0.w & (PK_PRIM - 1u);
+    HitRec h;
+    h.px = r.ox + r.dx * t;  // Ray::get_point (lib.rs:27-29)
+    h.py = r.oy + r.dy * t;
+    h.pz = r.oz + r.dz * t;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.mat = 0u;
+    h.prim_id = 0u;
+    float nx, ny, nz;
+    if (kind == ENT_SPHERE) {
+        const float cx = as_f(s0.x) + as_f(s1.x) * r.time;
+        const float cy = as_f(s0.y) + as_f(s1.y) * r.time;
+        const float cz = as_f(s0.z) + as_f(s1.z) * r.time;
+        const float radius = as_f(s1.w);
+        if (EXACT) {
+            nx = (h.px - cx) / radius;
+            ny = (h.py - cy) / radius;
+            nz = (h.pz - cz) / radius;
+        } else {
+            const float inv_r = __builtin_amdgcn_rcpf(radius);
+            nx = (h.px - cx) * inv_r;
+            ny = (h.py - cy) * inv_r;
+            nz = (h.pz - cz) * inv_r;
+        }
+        if (WANT_UV) sphere_uv(nx, ny, nz, h.u, h.v);
+        if (IDS) {
+            h.mat = __float_as_uint(S.sph[2 * pi + 1].w);
+            h.prim_id = S.sph_id[pi];
+        }
+    } else {
+        nx = as_f(s0.x);
+        ny = as_f(s0.y);
+        nz = as_f(s0.z);
+        if (WANT_UV || IDS) {
+            const uint4 su = ld(2), sv = ld(3);
+            if (WANT_UV) {
+                const uint4 sw = ld(4);
+                const float dx = h.px - as_f(s1.x), dy = h.py - as_f(s1.y), dz = h.pz - as_f(s1.z);
+                const float ux = as_f(su.x), uy = as_f(su.y), uz = as_f(su.z), vx = as_f(sv.x), vy = as_f(sv.y), vz = as_f(sv.z);
+                h.u = dot3(as_f(sw.x), as_f(sw.y), as_f(sw.z), dy * vz - vy * dz, dz * vx - vz * dx, dx * vy - vx * dy);
+                h.v = dot3(as_f(sw.x), as_f(sw.y), as_f(sw.z), uy * dz - dy * uz, uz * dx - dz * ux, ux * dy - dx * uy);
+            }
+            h.mat = su.w;
+            h.prim_id = sv.w;
+        }
+    }
+    const bool front = dot3(r.dx, r.dy, r.dz, nx, ny, nz) < 0.0f;  // mesh.rs:40
     h.nx = front ? nx : -nx;
     h.ny = front ? ny : -ny;
     h.nz = front ? nz : -nz;

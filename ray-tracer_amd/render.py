@@ -214,7 +214,7 @@ class Scene:
             varr = np.ascontiguousarray(view, dtype=F)
             vp = varr.ctypes.data_as(capi.c_float_p)
         _check(rtx().rtx_traversal_dump(C.byref(self.desc), traversal, vp, grow, None, None, 0, C.byref(n)))
-        ents = np.zeros((n.value, 8), dtype=np.uint32)
+        ents = np.zeros((n.value, 4 if traversal == TRAVERSAL_FAST_FUSED else 8), dtype=np.uint32)  # packed form: 4 words per slot
         rank = np.zeros(n.value, dtype=np.uint32)
         _check(rtx().rtx_traversal_dump(C.byref(self.desc), traversal, vp, grow, ents.ctypes.data_as(capi.c_u32_p),
                                         rank.ctypes.data_as(capi.c_u32_p), n.value, C.byref(n)))
