@@ -633,7 +633,7 @@ class Reorder {
 // The form of the fast array the render kernels walk when the scene has no transform / medium brackets: 16-byte slots,
 //   box        half_boxes: 1 slot   6 halfs (centre x y z, half extent x y z), word 3 = first slot of the entry to jump
 //                                   to on a miss
-//              else:       2 slots  (centre.xyz as floats, miss link) (half extent.xyz as floats, 0)
+//              else:       2 slots  (centre.xyz as floats, miss link as a BYTE offset) (half extent.xyz as floats, 0)
 //   sphere     2 slots  (c0.xyz, tag) (dc.xyz, r)
 //   quad/tri   5 slots  (n.xyz, tag) (Q.xyz, d) (u.xyz, material) (v.xyz, prim id) (w.xyz, 0)
 //   end        1 slot   word 3 = ENT_END
@@ -747,7 +747,7 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
                 w[a] = fbits(c);
                 w[4 + a] = fbits(h);
             }
-            w[3] = first[e.w[6]];
+            w[3] = first[e.w[6]] * PK_SLOT_BYTES;  // these arrays live in LDS: the link is the LDS address to continue at
             w[7] = 0;
             continue;
         }

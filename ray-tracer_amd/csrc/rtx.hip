@@ -595,10 +595,10 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
         if (e.w == ENT_END) break;
         if (e.w < PK_PRIM) {
             const bool hit = S.pk_half ? pk_slab_hit(e, rc, tmin, best.t) : pk_slab_hit(e, slots.at(off + PK_SLOT), rc, tmin, best.t);
-            off = hit ? off + (S.pk_half ? PK_SLOT : 2u * PK_SLOT) : e.w * PK_SLOT;
+            off = hit ? off + (S.pk_half ? PK_SLOT : 2u * PK_SLOT) : (S.pk_half ? e.w * PK_SLOT : e.w);  // float boxes carry byte links
         } else {
             const uint32_t at = off;
-            off += pk_prim_test(e, slots.at(off + PK_SLOT), [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); }, off, r, rc, tmin, best, rank);
+            off += pk_prim_test<false>(e, slots.at(off + PK_SLOT), [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); }, off, r, rc, tmin, best, rank);
         }
     }
     rtx_hit_t out;
@@ -734,7 +734,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     }
     if (ENTS_IN_LDS || TEX) __syncthreads();
 
-    const rtx_camera_t& C = P.cam;
+    // The kernel arguments once more, as they lie in the kernarg segment.  Values the walk loops need (scheduler
+    // constants, a pointer or two) are read from P and stay in scalar registers; everything a stage needs only when it
+    // runs -- camera, item geometry, table pointers -- is read through RTX_ARGS() where it is used, so that it is
+    // re-loaded there (scalar loads from a hot line) instead of occupying scalar registers across the whole loop: the
+    // lean variants have 80 of them per wave, and what does not fit is spilled into vector registers.
+    typedef __attribute__((address_space(4))) const RenderParams KArgs;
+    KArgs* const kargs = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#define RTX_ARGS()                        \
+    [&] {                                 \
+        KArgs* p_ = kargs;                \
+        asm volatile("" : "+s"(p_));      \
+        return p_;                        \
+    }()
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     uint32_t rays_traced = 0;  // per lane; summed in 64 bits at the end
     uint32_t wave_box = 0, wave_prim = 0;  // wave-uniform: lanes x steps of the box / primitive stage = tests performed
@@ -840,16 +852,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 
 #define RTX_CLAIM(ctx, sel)                                                                                      \
     do {                                                                                                         \
+        KArgs* q_ = RTX_ARGS();                                                                                  \
         uint32_t item_ = 0;                                                                                      \
-        if (lane == 0) item_ = atomicAdd(P.item_counter, 1u);                                                    \
+        if (lane == 0) item_ = atomicAdd(q_->item_counter, 1u);                                                  \
         item_ = __builtin_amdgcn_readfirstlane(item_);                                                           \
-        if (item_ >= P.n_items) {                                                                                \
+        if (item_ >= q_->n_items) {                                                                              \
             more = false;                                                                                        \
         } else {                                                                                                 \
-            const uint32_t tile_ = P.tile_rank + (item_ % P.n_owned) * P.tile_world;                             \
-            ctx.batch = item_ / P.n_owned;                                                                       \
-            ctx.txy = ((tile_ % P.tiles_x) * TILE) | (((tile_ / P.tiles_x) * TILE) << 16);                       \
-            ctx.pool_total = 64u * min(P.batch, P.sample_end - (P.sample_begin + ctx.batch * P.batch));          \
+            const uint32_t tile_ = q_->tile_rank + (item_ % q_->n_owned) * q_->tile_world;                       \
+            ctx.batch = __builtin_amdgcn_readfirstlane(item_ / q_->n_owned);                                     \
+            ctx.txy = __builtin_amdgcn_readfirstlane(((tile_ % q_->tiles_x) * TILE) | (((tile_ / q_->tiles_x) * TILE) << 16)); \
+            ctx.pool_total = __builtin_amdgcn_readfirstlane(64u * min(q_->batch, q_->sample_end - (q_->sample_begin + ctx.batch * q_->batch))); \
             ctx.pool_next = 0;                                                                                   \
             acc[(sel) * ACC_FLOATS + lane] = 0.0f;                                                               \
             acc[(sel) * ACC_FLOATS + lane + 64] = 0.0f;                                                          \
@@ -869,18 +882,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 // retire A once no lane carries one of its paths: write the tile's sums into this batch's partial image
                 // (each pixel of each batch has exactly one writer)
                 if (__ballot(st != ST_IDLE && (slot >> 6) == a_sel) == 0ull) {
+                    KArgs* Q = RTX_ARGS();
                     const uint32_t a_tx = A.txy & 0xFFFFu, a_ty = A.txy >> 16;
-                    if (a_tx + (lane & 7u) < C.width && a_ty + (lane >> 3) < C.height) {
+                    if (a_tx + (lane & 7u) < Q->cam.width && a_ty + (lane >> 3) < Q->cam.height) {
                         const uint32_t px = a_tx + (lane & 7u), py = a_ty + (lane >> 3);
-                        float* dst = P.partial + ((size_t)A.batch * C.height * C.width + (size_t)py * C.width + px) * 3;
+                        float* dst = Q->partial + ((size_t)A.batch * Q->cam.height * Q->cam.width + (size_t)py * Q->cam.width + px) * 3;
                         dst[0] = acc[a_sel * ACC_FLOATS + lane * 3 + 0];
                         dst[1] = acc[a_sel * ACC_FLOATS + lane * 3 + 1];
                         dst[2] = acc[a_sel * ACC_FLOATS + lane * 3 + 2];
                     }
                     if ((wave_box | wave_prim) >= 0x40000000u) {  // keep the 32-bit tallies from wrapping on very long launches
                         if (lane == 0) {
-                            atomicAdd(P.ray_counter + 1, (unsigned long long)wave_box);
-                            atomicAdd(P.ray_counter + 2, (unsigned long long)wave_prim);
+                            atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
+                            atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
                         }
                         wave_box = 0;
                         wave_prim = 0;
@@ -922,15 +936,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         RTX_LOAD_SLOT(off, e);
                         if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
                     }
+                    uint32_t tests = 0;  // summed in the loop's own scalar and added to the wave's tally once per pass
                     do {
-                        wave_box += nb;
+                        tests += nb;
 #ifdef RTX_STAGE_COUNTERS
                         sc[0]++;
                         sc[1] += nb;
 #endif
                         if (here) {
                             const bool hit = ENTS_IN_LDS ? pk_slab_hit(e, e1, rc, tmin, best.t) : pk_slab_hit(e, rc, tmin, best.t);
-                            off = hit ? off + BOX_BYTES : st * PK_SLOT;
+                            off = hit ? off + BOX_BYTES : (ENTS_IN_LDS ? st : st * PK_SLOT);  // float boxes carry byte links
                             RTX_LOAD_SLOT(off, e);
                             if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
                             st = e.w;
@@ -938,6 +953,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         here = at_box(st);
                         nb = (uint32_t)__popcll(__ballot(here));
                     } while (nb * k1 >= n_fixed && nb > 0);
+                    wave_box += tests;
                 } else {
                     uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
                     if (st == ENT_BOX) RTX_LOAD_ENTRY(off, ea, eb);
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                             uint4 s0, s1;
                             RTX_LOAD_SLOT(off, s0);
                             RTX_LOAD_SLOT(off + PK_SLOT, s1);
-                            off += pk_prim_test(s0, s1, slot_of(off), off, ray, rc, tmin, best, rank);
+                            off += pk_prim_test<true>(s0, s1, slot_of(off), off, ray, rc, tmin, best, rank);
                             RTX_LOAD_STATE(off, st);
                         }
                     } else if (at_prim(st)) {  // neither box (0) nor done / idle
@@ -1009,6 +1025,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 sc[5] += n_done;
                 sc[6] += min(n_idle, pool_left);
 #endif
+                KArgs* Q = RTX_ARGS();
+                __attribute__((address_space(4))) const rtx_camera_t& C = Q->cam;
                 bool begin_walk = false;  // scattered and newly generated rays start their walk together, below
                 if (st == ENT_END) {
                     st = ST_IDLE;
@@ -1023,22 +1041,22 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                             const auto slots = slot_of(best.ent);
                             if (ENTS_IN_LDS) {
                                 // one read, indexed like the slots (issued first: it is the long one)
-                                const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.pk_shade) + 2u * best.ent);
+                                const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Q->S.pk_shade) + 2u * best.ent);
                                 s0 = srec[0];
                                 s1 = srec[1];
                             } else {
                                 // large scenes keep no per-slot table: the entry names its material (a sphere through its record)
                                 const uint4 first = slots(0);
-                                const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(S.sph[2u * (first.w & (PK_PRIM - 1u)) + 1u].w) : slots(2).w;
-                                s0 = S.mat_recs[2u * m];
-                                s1 = S.mat_recs[2u * m + 1u];
+                                const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(Q->S.sph[2u * (first.w & (PK_PRIM - 1u)) + 1u].w) : slots(2).w;
+                                s0 = Q->S.mat_recs[2u * m];
+                                s1 = Q->S.mat_recs[2u * m + 1u];
                             }
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
                             h = want_uv ? pk_make_hit<true, false, false>(S, slots, ray, best.t) : pk_make_hit<false, false, false>(S, slots, ray, best.t);
                         } else {
                             // one read, indexed like the entries (issued first: it is the long one)
-                            const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.shade[M]) + best.ent);
+                            const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Q->S.shade[M]) + best.ent);
                             s0 = srec[0];
                             s1 = srec[1];
                             uint4 ha, hb;
@@ -1077,8 +1095,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                             bb *= so.ab;
                             depth_left--;
                             bool alive = depth_left > 0;
-                            if (P.rr_start != 0u) {  // wave-uniform: the reference has no Russian roulette
-                                if (alive && (C.max_depth - depth_left) >= P.rr_start) {
+                            if (Q->rr_start != 0u) {  // wave-uniform: the reference has no Russian roulette
+                                if (alive && (C.max_depth - depth_left) >= Q->rr_start) {
                                     // on the largest |throughput| component (albedos may be negative)
                                     const float q = fminf(1.0f, fmaxf(fmaxf(fabsf(br), fabsf(bg)), fabsf(bb)));
                                     if (rng_f32(rng) >= q) {
@@ -1107,14 +1125,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                     const uint32_t g_next = a_has ? A.pool_next : B.pool_next, g_total = a_has ? A.pool_total : B.pool_total;
                     const uint32_t g_txy = a_has ? A.txy : B.txy, g_batch = a_has ? A.batch : B.batch;
                     const uint32_t g_tx = g_txy & 0xFFFFu, g_ty = g_txy >> 16;
-                    const uint32_t g_s0 = P.sample_begin + g_batch * P.batch, g_sel = a_has ? a_sel : (a_sel ^ 1u);
+                    const uint32_t g_s0 = Q->sample_begin + g_batch * Q->batch, g_sel = a_has ? a_sel : (a_sel ^ 1u);
                     const uint32_t my = g_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     const uint32_t my_slot = my & 63u;
                     const uint32_t x = g_tx + (my_slot & 7u), y = g_ty + (my_slot >> 3);
                     if (st == ST_IDLE && my < g_total && x < C.width && y < C.height) {
                         slot = my_slot | (g_sel << 6);
                         const uint32_t sample = g_s0 + (my >> 6);
-                        rng = rng_init(P.seed0, P.seed1, y * C.width + x, sample);
+                        rng = rng_init(Q->seed0, Q->seed1, y * C.width + x, sample);
                         const float ox = rng_f32(rng) - 0.5f;
                         const float oy = rng_f32(rng) - 0.5f;
                         const float fx = (float)x + ox, fy = (float)y + oy;
@@ -1140,7 +1158,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         // ray_color(depth 0) is black before any hit test (camera.rs:125): the lane stays free
                         begin_walk = depth_left != 0;
                     }
-                    const uint32_t g_adv = min(g_total, g_next + (uint32_t)__popcll(idle));
+                    const uint32_t g_adv = __builtin_amdgcn_readfirstlane(min(g_total, g_next + (uint32_t)__popcll(idle)));
                     if (a_has) A.pool_next = g_adv; else B.pool_next = g_adv;
                 }
                 if (begin_walk) RTX_BEGIN_WALK();
@@ -1157,9 +1175,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     unsigned long long wave_rays = rays_traced;
     for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
     if (lane == 0) {
-        if (wave_rays) atomicAdd(P.ray_counter, wave_rays);
-        if (wave_box) atomicAdd(P.ray_counter + 1, (unsigned long long)wave_box);
-        if (wave_prim) atomicAdd(P.ray_counter + 2, (unsigned long long)wave_prim);
+        KArgs* Q = RTX_ARGS();
+        if (wave_rays) atomicAdd(Q->ray_counter, wave_rays);
+        if (wave_box) atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
+        if (wave_prim) atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
     }
 #ifdef RTX_STAGE_COUNTERS
     tc[3] = __builtin_readcyclecounter() - t_begin;
@@ -1170,6 +1189,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 #endif
 #undef RTX_TIC
 #undef RTX_TOC
+#undef RTX_ARGS
 }
 
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ partial, uint32_t n_batches, size_t n, float* __restrict__ accum, uint32_t width,
@@ -1359,7 +1379,8 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
 
     const bool pk = M == RTX_TRAVERSAL_FAST && scene->packed;  // (a scene with brackets has no packed array)
     const size_t ent_bytes = pk ? (size_t)scene->pk_slots * 16 : (size_t)scene->n_ents[M] * 32;
-    const bool in_lds = ent_bytes <= K.lds_ents_max;
+    // (a packed array has float boxes exactly when it was sized for LDS, and the kernel variants read it accordingly)
+    const bool in_lds = pk ? !scene->pk_half : ent_bytes <= K.lds_ents_max;
     // one instantiation per (traversal, entries in LDS, brackets, uv / noise textures): features a scene does not use
     // cost registers, and registers cost resident waves
     static void (*const kernels[16])(RenderParams) = {
@@ -1439,7 +1460,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 #ifdef RTX_STAGE_COUNTERS
         unsigned long long sc[12];
-        HIP_TRY(hipMemcpy(sc, scratch->counters + 2 + 6, 96, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sc, reinterpret_cast<unsigned long long*>(scratch->counters + 2) + 6, 96, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[stage clocks] box %.1f%% primitive %.1f%% service %.1f%% scheduling and item turnover %.1f%% of the waves' time\n", 100.0 * sc[8] / sc[11],
                      100.0 * sc[9] / sc[11], 100.0 * sc[10] / sc[11], 100.0 * (sc[11] - sc[8] - sc[9] - sc[10]) / sc[11]);
         double r = (double)cnt[0];

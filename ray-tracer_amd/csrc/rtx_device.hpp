@@ -224,9 +224,15 @@ __device__ __forceinline__ bool in_range(float t, float tmin, const Best& b, uin
 }
 
 // Sphere::hit up to the accepted root (mesh.rs:113-133).
-template <bool STRICT, int SHIFT = 5>
+//  QUICK : the two roots through the hardware square root and reciprocal (about 1 ulp each) instead of the correctly
+//          rounded sqrt and two divisions, which expand to ~35 instructions.  t then differs from the reference's by a
+//          few ulps -- far inside the 1e-5 tolerance on hit distances -- so only the render kernels' fast walk uses it;
+//          rtx_trace, the parity gate for ids and t, always computes the roots exactly.  Equal inputs still give equal
+//          roots, so coincident primitives tie as before.
+template <bool STRICT, int SHIFT = 5, bool QUICK = false>
 __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, Best& best,
                                             uint32_t idx, const uint32_t* __restrict__ rank) {
+    static_assert(!(STRICT && QUICK), "the strict walk reproduces the reference's arithmetic");
     float cx = as_f(ea.x) + as_f(ea.w) * r.time;  // center(time) = initial_center + center_delta * time (mesh.rs:178-180)
     float cy = as_f(ea.y) + as_f(eb.x) * r.time;
     float cz = as_f(ea.z) + as_f(eb.y) * r.time;
@@ -236,17 +242,26 @@ __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, co
     float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - radius * radius;
     float disc = h * h - rc.a * c;
     if (disc < 0.0f) return;
-    float sqrtd = __builtin_sqrtf(disc);
-    float root = (h - sqrtd) / rc.a;
-    if (STRICT) {
-        if (!in_range<true, SHIFT>(root, tmin, best, idx, rank)) {
-            root = (h + sqrtd) / rc.a;
-            if (!in_range<true, SHIFT>(root, tmin, best, idx, rank)) return;
-        }
-    } else {
-        // the first root inside [tmin, end) is the near one unless it lies before tmin
-        if (!(tmin <= root)) root = (h + sqrtd) / rc.a;
+    float root;
+    if (QUICK) {
+        const float sqrtd = __builtin_amdgcn_sqrtf(disc);
+        const float inv_a = __builtin_amdgcn_rcpf(rc.a);
+        root = (h - sqrtd) * inv_a;
+        if (!(tmin <= root)) root = (h + sqrtd) * inv_a;
         if (!in_range<false, SHIFT>(root, tmin, best, idx, rank)) return;
+    } else {
+        const float sqrtd = __builtin_sqrtf(disc);
+        root = (h - sqrtd) / rc.a;
+        if (STRICT) {
+            if (!in_range<true, SHIFT>(root, tmin, best, idx, rank)) {
+                root = (h + sqrtd) / rc.a;
+                if (!in_range<true, SHIFT>(root, tmin, best, idx, rank)) return;
+            }
+        } else {
+            // the first root inside [tmin, end) is the near one unless it lies before tmin
+            if (!(tmin <= root)) root = (h + sqrtd) / rc.a;
+            if (!in_range<false, SHIFT>(root, tmin, best, idx, rank)) return;
+        }
     }
     best.t = root;
     best.ent = idx;
@@ -409,13 +424,13 @@ __device__ __forceinline__ float4 as_f4(const uint4& u) { return make_float4(as_
 
 // Primitive test at the packed entry whose first two slots are s0, s1 (byte offset off); LD(k) reads slot k of it.
 // Returns the entry's size in bytes.
-template <class LD>
+template <bool QUICK, class LD>
 __device__ __forceinline__ uint32_t pk_prim_test(const uint4& s0, const uint4& s1, LD ld, uint32_t off, const Ray& r, const RayConst& rc, float tmin,
                                                  Best& best, const uint32_t* __restrict__ rank) {
     const uint32_t kind = s0.w >> 28;
     if (kind == ENT_SPHERE) {
         // slots (c0.xyz, tag) (dc.xyz, r) in the word order sphere_test reads an unpacked entry
-        sphere_test<false, 4>(make_uint4(s0.x, s0.y, s0.z, s1.x), make_uint4(s1.y, s1.z, s1.w, 0u), r, rc, tmin, best, off, rank);
+        sphere_test<false, 4, QUICK>(make_uint4(s0.x, s0.y, s0.z, s1.x), make_uint4(s1.y, s1.z, s1.w, 0u), r, rc, tmin, best, off, rank);
         return 2u * PK_SLOT;
     }
     // slots (n, tag) (Q, d) (u, material) (v, prim id) (w, 0) -> records 0 Q  1 u  2 v  3 n  4 w

@@ -156,6 +156,9 @@ def walk_packed(slots, rank, ray, half_boxes, tmin=F(0.001)):
         if tag == ENT_END:
             break
         if tag < PK_PRIM:
+            if not half_boxes:
+                assert tag % 16 == 0
+                tag //= 16  # float boxes carry their miss link as a byte offset
             assert tag > i, "miss links point forward"
             if half_boxes:  # one slot: six halfs
                 h = np.array(slots[i, :3], dtype=np.uint32).view(np.float16).astype(np.float64)
