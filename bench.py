@@ -59,7 +59,10 @@ def measured_hbm_traffic(workload_is_default):
 
     if not workload_is_default:
         return None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.csv")), reverse=True):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_hbm_counters.csv")), reverse=True)  # C2 = the default workload
+    for path in paths + [os.path.join(ROOT, "profiles", "r1_final_hbm_counters.csv")]:
+        if not os.path.exists(path):
+            continue
         kb = {}
         with open(path) as f:
             for row in csv.DictReader(f):
