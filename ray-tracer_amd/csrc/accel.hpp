@@ -40,7 +40,7 @@ namespace rtx_accel {
 enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3, ENT_XF_PUSH = 4, ENT_XF_POP = 5, ENT_MED_BEGIN = 6, ENT_MED_END = 7 };
 constexpr uint32_t ENT_END = 0xFFFFFFFEu;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int MAX_XF_DEPTH = 3;  // nested Translate / RotateY levels the kernels re-apply when they leave a transform
+constexpr int MAX_XF_DEPTH = 64;  // nested Translate / RotateY levels accepted (the kernels walk the chain of enclosing transforms)
 
 struct Ent {
     uint32_t w[8];
@@ -232,7 +232,7 @@ class Builder {
             out.mat.push_back(o.material);
             out.n_prims++;
         } else {
-            if (xf_depth >= MAX_XF_DEPTH) return fail("Translate / RotateY nested deeper than 3 levels", true);
+            if (xf_depth >= MAX_XF_DEPTH) return fail("Translate / RotateY nested deeper than 64 levels", true);
             a.w[0] = o.kind == RTX_OBJ_TRANSLATE ? 1u : 2u;
             a.w[1] = fbits(o.f[0]);
             a.w[2] = fbits(o.f[1]);

@@ -543,23 +543,36 @@ __device__ __forceinline__ void xf_apply(const uint4& ea, Ray& r) {
         r.dz = dz;
     }
 }
-// The ray as seen inside transform-enter entry `xf` (and all transforms enclosing it), derived from the world ray.
+// The ray as seen inside transform-enter entry `xf` (and all transforms enclosing it), derived from the world ray: the
+// enclosing transforms are applied outermost first, as the nested hit() calls of the reference do (mesh.rs:332, :365-372).
+// An entry only links to its parent, so the chain is walked once to count it and then once per level from the top;
+// nesting is shallow (two levels in the reference's scenes), and any depth the host accepts works.
+constexpr int XF_MAX_DEPTH = 64;  // the host rejects deeper nesting (rtx_accel::MAX_XF_DEPTH)
 __device__ inline Ray xf_chain_ray(const EntReader& ents, uint32_t xf, const Ray& w) {
-    uint32_t x0 = xf, x1 = XF_NONE, x2 = XF_NONE;
-    uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0, a2 = a0, b2 = a0;
-    if (x0 != XF_NONE) {
-        ents.load(x0, a0, b0);
-        x1 = b0.x;
-    }
-    if (x1 != XF_NONE) {
-        ents.load(x1, a1, b1);
-        x2 = b1.x;
-    }
-    if (x2 != XF_NONE) ents.load(x2, a2, b2);
     Ray r = w;
-    if (x2 != XF_NONE) xf_apply(a2, r);
-    if (x1 != XF_NONE) xf_apply(a1, r);
-    if (x0 != XF_NONE) xf_apply(a0, r);
+    if (xf == XF_NONE) return r;
+    uint4 a, b;
+    ents.load(xf, a, b);
+    if (b.x == XF_NONE) {  // one level: the common case
+        xf_apply(a, r);
+        return r;
+    }
+    int depth = 1;
+    for (uint32_t x = b.x; x != XF_NONE && depth < XF_MAX_DEPTH; depth++) {
+        uint4 pa, pb;
+        ents.load(x, pa, pb);
+        x = pb.x;
+    }
+    for (int level = depth - 1; level >= 0; level--) {  // level 0 is xf itself, depth - 1 the outermost
+        uint32_t x = xf;
+        uint4 ta, tb;
+        ents.load(x, ta, tb);
+        for (int k = 0; k < level; k++) {
+            x = tb.x;
+            ents.load(x, ta, tb);
+        }
+        xf_apply(ta, r);
+    }
     return r;
 }
 
@@ -661,7 +674,7 @@ __device__ inline HitRec make_hit_x(const DevScene& S, const EntReader& ents, co
         h = make_hit<WANT_UV, EXACT>(S, ha, hb, lr, best.t);
     }
     uint32_t xf = best_xf;
-    for (int level = 0; level < 3 && xf != XF_NONE; level++) {
+    for (int level = 0; level < XF_MAX_DEPTH && xf != XF_NONE; level++) {  // innermost first, as the calls return
         uint4 a, b;
         ents.load(xf, a, b);
         if (a.x == 1u) {

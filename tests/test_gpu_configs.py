@@ -260,3 +260,45 @@ def test_work_counters_and_stats(render, scenes):
     assert 5 < f1.box_tests / f1.rays < 60 and 0.5 < f1.prim_tests / f1.rays < 10
     assert abs(s.rays - f1.rays) < 0.01 * f1.rays and s.box_tests > 2 * f1.box_tests  # the reference's origin-including boxes cull far less
     assert f1.flags & 1  # a few hundred spheres: entries resident in LDS
+
+
+# ------------------------------------------------------------------------------------------------ deep instancing
+def _nested_scene(scene):
+    """Five nested Translate / RotateY levels around a cube and four around a sphere (the reference nests them freely,
+    mesh.rs:324-432), beside plain primitives."""
+    white = scene.Lambertian.rgb(0.73, 0.73, 0.73)
+    cube = scene.Cube((0, 0, 0), (1.2, 1.6, 1.2), white)
+    for k, (angle, off) in enumerate([(15.0, (0.3, 0.0, -0.2)), (-28.0, (-0.4, 0.1, 0.5)), (40.0, (0.6, 0.0, 0.1))]):
+        cube = scene.Translate(scene.RotateY(cube, angle), off) if k < 2 else scene.RotateY(cube, angle)  # T(R(T(R(R(cube))))) = 5 levels
+    ball = scene.Sphere.stationary((0.0, 0.5, 0.0), 0.5, scene.Metal.rgb(0.8, 0.7, 0.6).with_roughness(0.05))
+    ball = scene.Translate(scene.RotateY(scene.Translate(scene.RotateY(ball, 33.0), (1.0, 0.0, 0.0)), -70.0), (-2.0, 0.0, 1.0))
+    w = scene.World()
+    w.push(scene.Sphere.stationary((0.0, -1000.0, 0.0), 1000.0, scene.Lambertian.rgb(0.5, 0.6, 0.5)))
+    w.push(cube)
+    w.push(ball)
+    w.push(scene.Sphere.stationary((2.2, 0.6, 0.4), 0.6, scene.Dielectric(1.5)))
+    cfg = scene.CameraConfig(width=160, height=120, samples_per_pixel=8, max_depth=20, vfov=35.0, lookfrom=(6.0, 3.0, 7.0),
+                             lookat=(0.0, 0.7, 0.0), vup=(0, 1, 0))
+    return cfg, scene.Bvh(w)
+
+
+def test_deeply_nested_transforms_match_oracle(render, oracle, scene, capi):
+    cfg, bvh = _nested_scene(scene)
+    om, gs = oracle.OracleMesh(bvh), render.Scene(bvh)
+    prim = oracle.OracleCamera(cfg).center_rays(0.5)
+    want = om.trace(prim)
+    assert len(set(want["prim_id"][want["prim_id"] != MISS].tolist())) >= 5  # ground, cube faces, both wrapped objects
+    rays = np.concatenate([prim, _surface_rays(capi, want, 30_000, 2)])
+    want = om.trace(rays)
+    got = gs.trace(rays, traversal=render.TRAVERSAL_STRICT)
+    assert np.array_equal(got["prim_id"], want["prim_id"])
+    hit = want["prim_id"] != MISS
+    for f in ("t", "n", "p"):  # the wrong back-rotation of RotateY (mesh.rs:378-382) is applied once per level, as the reference does
+        assert np.array_equal(got[f][hit], want[f][hit]), f
+    for mode in (render.TRAVERSAL_FAST, render.TRAVERSAL_FAST_FUSED):
+        fast = gs.trace(rays, traversal=mode)
+        assert np.count_nonzero(fast["prim_id"] != want["prim_id"]) <= 2
+    ref, _ = oracle.OracleCamera(cfg).render(om, seed=5, rng_kind=1)
+    _, acc = render.Camera(cfg).render(gs, seed=5, traversal=render.TRAVERSAL_STRICT, want_accum=True)
+    rel = np.abs(acc - ref) / (np.abs(ref) + 1e-2 * cfg.samples_per_pixel)
+    assert np.median(rel) < 1e-3 and np.mean(rel < 2e-2) > 0.95

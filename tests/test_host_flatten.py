@@ -111,3 +111,36 @@ def test_triangle_mesh_flattens_like_the_oracle(render, oracle, scenes):
     assert hs.desc.n_tris == 4 * 12 * 11 and hs.n_prims == om.n_prims == 1 + 4 * 12 * 11
     assert np.array_equal(hs.leaf_order(), om.leaf_order())
     assert np.array_equal(hs.node_boxes(), om.node_boxes())
+
+
+def test_unsupported_scene_graphs_are_refused_not_mis_rendered(render, scene):
+    """What the traversal data cannot express is refused when it is built (RTX_ERR_UNSUPPORTED), host side, no GPU needed:
+    a ConstantMedium inside the boundary of another one (mesh.rs:627-696 would nest them), and transforms nested deeper
+    than the kernels' limit of 64."""
+    white = scene.Lambertian.rgb(0.7, 0.7, 0.7)
+    ball = scene.Sphere.stationary((0, 0, 0), 1.0, white)
+    inner = scene.ConstantMedium.from_color(ball, 0.5, (1, 1, 1))
+    w = scene.World()
+    w.push(scene.ConstantMedium.from_color(inner, 0.1, (0, 0, 0)))
+    w.push(scene.Sphere.stationary((3, 0, 0), 1.0, white))
+    with pytest.raises(render.RtxError) as e:
+        render.Scene(scene.Bvh(w), upload=False).traversal_dump(render.TRAVERSAL_FAST)
+    assert e.value.code == render.RTX_ERR_UNSUPPORTED and "ConstantMedium" in str(e.value)
+    obj = ball
+    for k in range(65):
+        obj = scene.Translate(obj, (0.01, 0.0, 0.0)) if k % 2 else scene.RotateY(obj, 1.0)
+    w = scene.World()
+    w.push(obj)
+    w.push(scene.Sphere.stationary((3, 0, 0), 1.0, white))
+    with pytest.raises(render.RtxError) as e:
+        render.Scene(scene.Bvh(w), upload=False).traversal_dump(render.TRAVERSAL_STRICT)
+    assert e.value.code == render.RTX_ERR_UNSUPPORTED and "64" in str(e.value)
+    # 64 levels are accepted
+    obj = ball
+    for k in range(64):
+        obj = scene.Translate(obj, (0.01, 0.0, 0.0)) if k % 2 else scene.RotateY(obj, 1.0)
+    w = scene.World()
+    w.push(obj)
+    w.push(scene.Sphere.stationary((3, 0, 0), 1.0, white))
+    ents, _ = render.Scene(scene.Bvh(w), upload=False).traversal_dump(render.TRAVERSAL_STRICT)
+    assert np.count_nonzero((ents[:, 7] & 15) == 4) == 64
