@@ -57,8 +57,8 @@ static const Knobs& knobs() {
         x.view_order = u("RTX_VIEW_ORDER", 1);
         x.items_per_wave = u("RTX_ITEMS_PER_WAVE", 0);
         x.max_batches = u("RTX_MAX_BATCHES", 64);
-        x.sched_k = std::max(1u, u("RTX_SCHED_K", 4));
-        x.w_prim = std::max(1u, u("RTX_W_PRIM", 10));
+        x.sched_k = std::max(1u, u("RTX_SCHED_K", 6));
+        x.w_prim = std::max(1u, u("RTX_W_PRIM", 8));
         x.w_serv = std::max(1u, u("RTX_W_SERV", 3));
         x.sched_kp = u("RTX_SCHED_KP", 32);
         x.overlap = u("RTX_OVERLAP", 1);
