@@ -1028,7 +1028,45 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 KArgs* Q = RTX_ARGS();
                 __attribute__((address_space(4))) const rtx_camera_t& C = Q->cam;
                 bool begin_walk = false;  // scattered and newly generated rays start their walk together, below
-                if (st == ENT_END) {
+                // what a hit is shaded with (layout: DevScene::shade), indexed like the entries / slots
+                auto shade_rec = [&](uint4& s0, uint4& s1) {
+                    if (PK && !ENTS_IN_LDS) {
+                        // large scenes keep no per-slot table: the entry names its material (a sphere through its record)
+                        const auto slots = slot_of(best.ent);
+                        const uint4 first = slots(0);
+                        const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(Q->S.sph[2u * (first.w & (PK_PRIM - 1u)) + 1u].w) : slots(2).w;
+                        s0 = Q->S.mat_recs[2u * m];
+                        s1 = Q->S.mat_recs[2u * m + 1u];
+                    } else {
+                        const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(PK ? Q->S.pk_shade : Q->S.shade[M]) + (PK ? 2u * best.ent : best.ent));
+                        s0 = srec[0];
+                        s1 = srec[1];
+                    }
+                };
+                // Material bins (builds with -DRTX_MAT_BINS only; measured 28% slower on the benchmark scene): of the lanes
+                // waiting with a hit, only those of the most frequent material kind are shaded in this pass, so that the pass
+                // runs one material's code; the others keep waiting.
+                bool defer = false;
+#ifdef RTX_MAT_BINS
+                {
+                    uint32_t kind = 0xFFu;
+                    if (st == ENT_END && best.ent != NO_HIT) {
+                        uint4 s0, s1;
+                        shade_rec(s0, s1);
+                        kind = s0.x & 255u;
+                    }
+                    uint32_t top_kind = 0u, top_n = 0u;
+                    for (uint32_t k = 0; k <= RTX_MAT_ISOTROPIC; k++) {
+                        const uint32_t n = (uint32_t)__popcll(__ballot(kind == k));
+                        if (n > top_n) {
+                            top_n = n;
+                            top_kind = k;
+                        }
+                    }
+                    defer = kind != 0xFFu && kind != top_kind;
+                }
+#endif
+                if (st == ENT_END && !defer) {
                     st = ST_IDLE;
                     if (best.ent == NO_HIT) {
                         atomicAdd(&acc[slot * 3 + 0], br * C.background[0]);
@@ -1037,28 +1075,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                     } else {
                         HitRec h;
                         uint4 s0, s1;  // what the hit is shaded with (layout: DevScene::shade)
+                        shade_rec(s0, s1);  // issued first: it is the long read
                         if (PK) {
                             const auto slots = slot_of(best.ent);
-                            if (ENTS_IN_LDS) {
-                                // one read, indexed like the slots (issued first: it is the long one)
-                                const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Q->S.pk_shade) + 2u * best.ent);
-                                s0 = srec[0];
-                                s1 = srec[1];
-                            } else {
-                                // large scenes keep no per-slot table: the entry names its material (a sphere through its record)
-                                const uint4 first = slots(0);
-                                const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(Q->S.sph[2u * (first.w & (PK_PRIM - 1u)) + 1u].w) : slots(2).w;
-                                s0 = Q->S.mat_recs[2u * m];
-                                s1 = Q->S.mat_recs[2u * m + 1u];
-                            }
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
                             h = want_uv ? pk_make_hit<true, false, false>(S, slots, ray, best.t) : pk_make_hit<false, false, false>(S, slots, ray, best.t);
                         } else {
-                            // one read, indexed like the entries (issued first: it is the long one)
-                            const uint4* srec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Q->S.shade[M]) + best.ent);
-                            s0 = srec[0];
-                            s1 = srec[1];
                             uint4 ha, hb;
                             RTX_LOAD_ENTRY(best.ent, ha, hb);
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
