@@ -710,6 +710,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     static_assert(!PK || (!STRICT && !XF), "the packed array exists for the fast walk of bracket-free scenes only");
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
+    constexpr bool SCALED = PK && ENTS_IN_LDS;  // the walk runs in scaled ray parameters (pk_slab_hit_scaled); best.t is scaled too
     const DevScene& S = P.S;
     const uint4* __restrict__ gents = PK ? S.pk : S.ents[M];
     const uint32_t* __restrict__ rank = PK ? S.pk_rank : S.rank[M];
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 #define RTX_BEGIN_WALK()                 \
     do {                                 \
         rc = ray_const<SLAB>(ray);       \
+        if (SCALED) scale_ray_const(rc); \
         best.t = __builtin_inff();       \
         best.ent = NO_HIT;               \
         if (XF) {                        \
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         sc[1] += nb;
 #endif
                         if (here) {
-                            const bool hit = ENTS_IN_LDS ? pk_slab_hit(e, e1, rc, tmin, best.t) : pk_slab_hit(e, rc, tmin, best.t);
+                            const bool hit = ENTS_IN_LDS ? pk_slab_hit_scaled(e, e1, rc, best.t) : pk_slab_hit(e, rc, tmin, best.t);
                             off = hit ? off + BOX_BYTES : (ENTS_IN_LDS ? st : st * PK_SLOT);  // float boxes carry byte links
                             RTX_LOAD_SLOT(off, e);
                             if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
@@ -990,7 +992,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                             uint4 s0, s1;
                             RTX_LOAD_SLOT(off, s0);
                             RTX_LOAD_SLOT(off + PK_SLOT, s1);
-                            off += pk_prim_test<true>(s0, s1, slot_of(off), off, ray, rc, tmin, best, rank);
+                            Best real = best;  // the primitive tests work in the ray's own parameter
+                            if (SCALED) real.t = best.t * PK_T_UNSCALE;
+                            off += pk_prim_test<true>(s0, s1, slot_of(off), off, ray, rc, tmin, real, rank);
+                            best.ent = real.ent;
+                            best.t = SCALED ? real.t * PK_T_SCALE : real.t;
                             RTX_LOAD_STATE(off, st);
                         }
                     } else if (at_prim(st)) {  // neither box (0) nor done / idle
@@ -1080,7 +1086,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                             const auto slots = slot_of(best.ent);
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
-                            h = want_uv ? pk_make_hit<true, false, false>(S, slots, ray, best.t) : pk_make_hit<false, false, false>(S, slots, ray, best.t);
+                            const float t_hit = SCALED ? best.t * PK_T_UNSCALE : best.t;  // exact: the factor is a power of two
+                            h = want_uv ? pk_make_hit<true, false, false>(S, slots, ray, t_hit) : pk_make_hit<false, false, false>(S, slots, ray, t_hit);
                         } else {
                             uint4 ha, hb;
                             RTX_LOAD_ENTRY(best.ent, ha, hb);

@@ -415,6 +415,40 @@ __device__ __forceinline__ bool pk_slab_hit(const uint4& s0, const uint4& s1, co
     return !(exit <= enter);
 }
 
+// The render kernels with float boxes walk in scaled ray parameters t' = t * PK_T_SCALE: 1 / direction and -(origin / direction) carry the
+// factor, so every plane distance comes out scaled, and so is the interval end the caller passes.  The factor is a power
+// of two: all values are the unscaled ones with another exponent, and every comparison between them decides as before.
+// What the scaling buys is the interval start for free: the fused operation that yields the last near-plane distance
+// clamps its result to [0, 1] (an output modifier), which stands in for max(., tmin).  The start becomes 0 instead of
+// tmin, and near distances beyond t' = 1 -- t = 2^60, farther than any box of a scene a float can describe unless the
+// direction is shorter than ~1e-14 -- read as 1: both only ever accept a box the exact test would reject.
+constexpr float PK_T_SCALE = 0x1p-60f, PK_T_UNSCALE = 0x1p60f;
+__device__ __forceinline__ float fma_neg_abs_clamp01(float h, float inv, float c) {  // clamp(-h * |inv| + c, 0, 1)
+    float d;
+    asm("v_fma_f32 %0, -%1, |%2|, %3 clamp" : "=v"(d) : "v"(h), "v"(inv), "v"(c));
+    return d;
+}
+__device__ __forceinline__ void scale_ray_const(RayConst& rc) {
+    rc.ix *= PK_T_SCALE;
+    rc.iy *= PK_T_SCALE;
+    rc.iz *= PK_T_SCALE;
+    rc.nx *= PK_T_SCALE;
+    rc.ny *= PK_T_SCALE;
+    rc.nz *= PK_T_SCALE;
+}
+__device__ __forceinline__ bool pk_slab_hit_scaled(const uint4& s0, const uint4& s1, const RayConst& rc, float tmax_scaled) {
+    const float tcx = __builtin_fmaf(as_f(s0.x), rc.ix, rc.nx);
+    const float tcy = __builtin_fmaf(as_f(s0.y), rc.iy, rc.ny);
+    const float tcz = __builtin_fmaf(as_f(s0.z), rc.iz, rc.nz);
+    const float hx = as_f(s1.x), hy = as_f(s1.y), hz = as_f(s1.z);
+    const float ax = __builtin_fabsf(rc.ix), ay = __builtin_fabsf(rc.iy), az = __builtin_fabsf(rc.iz);
+    const float enter = fmaxf(fmaxf(__builtin_fmaf(-hx, ax, tcx), __builtin_fmaf(-hy, ay, tcy)), fma_neg_abs_clamp01(hz, rc.iz, tcz));
+    const float exit3 = fminf(fminf(__builtin_fmaf(hx, ax, tcx), __builtin_fmaf(hy, ay, tcy)), __builtin_fmaf(hz, az, tcz));
+    float exit;
+    asm("v_min_f32 %0, %1, %2" : "=v"(exit) : "v"(exit3), "v"(tmax_scaled));
+    return !(exit <= enter);
+}
+
 // Reads slots of the packed array through a generic pointer (trace kernel, rare paths).
 struct SlotReader {
     const uint4* base;
