@@ -1201,14 +1201,21 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 #undef RTX_LOAD_SLOT
 #undef RTX_LOAD_STATE
 #undef RTX_BEGIN_WALK
-    // one ray-count update per wave
+    // One update of the launch's tallies per block: thousands of waves adding to the same three words at the end of a
+    // launch take longer than a short launch itself.  Every wave leaves its sums in its own accumulator space.
     unsigned long long wave_rays = rays_traced;
     for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
+    unsigned long long* const tally = reinterpret_cast<unsigned long long*>(acc);
     if (lane == 0) {
-        KArgs* Q = RTX_ARGS();
-        if (wave_rays) atomicAdd(Q->ray_counter, wave_rays);
-        if (wave_box) atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
-        if (wave_prim) atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
+        tally[0] = wave_rays;
+        tally[1] = wave_box;
+        tally[2] = wave_prim;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        unsigned long long sum = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) sum += reinterpret_cast<const unsigned long long*>(reinterpret_cast<float*>(smem + ent_u4) + w * (2 * ACC_FLOATS))[threadIdx.x];
+        if (sum) atomicAdd(RTX_ARGS()->ray_counter + threadIdx.x, sum);
     }
 #ifdef RTX_STAGE_COUNTERS
     tc[3] = __builtin_readcyclecounter() - t_begin;
