@@ -200,6 +200,36 @@ def test_resolve_matches_oracle_transfer(render, oracle, scenes):
     assert diff.max() <= 1 and np.mean(diff == 0) > 0.999
 
 
+def test_resolve_differs_from_oracle_only_at_rounding_thresholds(render, oracle, scenes):
+    """The sRGB transfer goes through powf on both sides (glibc in the oracle, the device library in the kernel), whose
+    results can differ in the last place.  4 M inputs across [0, 1.05] plus special values: wherever a byte differs it
+    differs by one level and the exact transfer value lies within 1e-4 levels of a rounding threshold (k + 0.5);
+    everywhere else, and for zero, negative, > 1, infinite and NaN inputs, the bytes are equal."""
+    import torch
+
+    n = 1 << 22
+    v = np.linspace(0.0, 1.05, n, dtype=np.float64).astype(F)
+    special = np.array([0.0, -0.0, -1.0, -np.inf, np.inf, np.nan, 1.0, 2.0, 0.0031308, np.nextafter(F(0.0031308), F(1)), 1e-30, 3e38], dtype=F)
+    v[: len(special)] = special
+    cfg, _ = scenes.make("default", seed=0, width=2048, height=n // 3 // 2048, samples_per_pixel=1)
+    cam = render.Camera(cfg)
+    m = cfg.width * cfg.height * 3
+    v = v[:m]
+    acc = torch.from_numpy(v).cuda()
+    out = torch.zeros(m, dtype=torch.uint8, device="cuda")
+    cam.resolve(acc.data_ptr(), out.data_ptr(), scale=1.0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.int32)
+    want = oracle.resolve(v.reshape(-1, 3), 1.0).reshape(-1).astype(np.int32)
+    assert np.array_equal(got[: len(special)], want[: len(special)])
+    diff = got != want
+    assert np.abs(got - want).max() <= 1
+    x = v[diff].astype(np.float64)
+    exact = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1.0 / 2.4) - 0.055) * 255.0
+    assert np.all(np.abs(exact - np.floor(exact) - 0.5) < 1e-4), "a byte differs away from a rounding threshold"
+    assert diff.mean() < 1e-4
+
+
 def test_sample_ranges_add_up_and_runs_repeat(render, scenes):
     import torch
 
@@ -413,9 +443,12 @@ def test_instanced_scene_renders_match_oracle(render, oracle, scenes, name, spp)
     scene, cam = render.Scene(bvh), render.Camera(cfg)
     _, acc = cam.render(scene, seed=5, traversal=render.TRAVERSAL_STRICT, want_accum=True)
     rel = np.abs(acc - ref) / (np.abs(ref) + 5e-2 * spp)
-    assert np.median(rel) < 1e-3, (name, float(np.median(rel)))
-    assert np.mean(rel < 5e-2) > 0.93, (name, float(np.mean(rel < 5e-2)))
-    assert abs(acc.mean() - ref.mean()) < 0.05 * abs(ref.mean()) + 1e-3, name
-    # the fast walk is the same estimator with another visiting order: its mean agrees
+    # measured: cornell-box identical but for rounding, cornell-smoke 99.96 % and final-scene 99.89 % of the values within
+    # 1e-3 (a free-flight distance goes through logf, which differs by ulps and now and then flips a decision)
+    assert np.median(rel) < 1e-6, (name, float(np.median(rel)))
+    assert np.mean(rel < 1e-3) > 0.995, (name, float(np.mean(rel < 1e-3)))
+    assert abs(acc.mean() - ref.mean()) < 1e-3 * abs(ref.mean()), name
+    # the fast walk is the same estimator with another visiting order: its mean agrees within the estimator's noise
+    # at this size (the oracle's own seed-to-seed difference of the mean is 0.5 - 1.4 %)
     _, fast = cam.render(scene, seed=6, traversal=render.TRAVERSAL_FAST, want_accum=True)
-    assert abs(fast.mean() - ref.mean()) < 0.08 * abs(ref.mean()) + 1e-3, name
+    assert abs(fast.mean() - ref.mean()) < 0.04 * abs(ref.mean()), name
