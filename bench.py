@@ -49,18 +49,21 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3
 HBM_PEAK_TBS = 8.0
 
 
-def measured_hbm_traffic(workload_is_default):
-    """(bytes, file) -- HBM bytes of one render_kernel launch of the default workload from the newest committed
-    rocprofv3 PMC passes under profiles/ (FETCH_SIZE and WRITE_SIZE are collected in separate runs; FETCH_SIZE counts
-    64 B per 128-B request on gfx950 and is doubled).  A PMC pass cannot run inside this process, so this is the one
-    figure of the line that is not measured live; the file it came from is named beside it."""
+def measured_hbm_traffic(tag):
+    """(bytes, file) -- HBM-side bytes of one render_kernel launch of a profiled workload (tag "c2" = the default
+    workload, "c4" = the million-triangle configuration) from the newest committed rocprofv3 PMC passes under profiles/
+    (FETCH_SIZE and WRITE_SIZE are collected in separate runs; FETCH_SIZE counts 64 B per 128-B request on gfx950 and is
+    doubled).  A PMC pass cannot run inside this process, so this is the one figure of the line that is not measured
+    live; the file it came from is named beside it."""
     import csv
     import glob
 
-    if not workload_is_default:
+    if tag is None:
         return None, None
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_hbm_counters.csv")), reverse=True)  # C2 = the default workload
-    for path in paths + [os.path.join(ROOT, "profiles", "r1_final_hbm_counters.csv")]:
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_hbm_counters.csv")), reverse=True)
+    if tag == "c2":
+        paths.append(os.path.join(ROOT, "profiles", "r1_final_hbm_counters.csv"))
+    for path in paths:
         if not os.path.exists(path):
             continue
         kb = {}
@@ -107,8 +110,12 @@ def main():
     ap.add_argument("--rr", type=int, default=0, help="Russian roulette start depth (0 = off, as in the reference)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-scale", type=int, default=1, help="CPU legs (event counts and baseline) render width/N x height/N of the same camera: "
+                                                             "per-sample figures do not depend on the resolution (large scenes)")
     ap.add_argument("--mesh-nlat", type=int, default=0, help="triangle-mesh / mixed scenes: latitude rings of the synthetic mesh (500 = 998k triangles)")
     ap.add_argument("--save", default=None, help="write the frame to this PNG (rank 0)")
+    ap.add_argument("--work-counts", default=None, help="write the event counts the roofline is priced with (oracle events per sample, "
+                                                        "the kernel's own tests of this run) to this JSON file")
     ap.add_argument("--in-library", action="store_true",
                     help="multi-GPU through the C ABI instead of one process per GPU: ONE process, rtx_render_multi drives --gpus devices")
     args = ap.parse_args()
@@ -214,7 +221,7 @@ def main():
             out["pcie_inclusive"] = {"value": round(cfg.width * cfg.height * args.spp / dt / 1e6, 2), "unit": "Msamples/s", "ms": round(dt * 1e3, 3),
                                      "note": "one rtx_render call with host buffers: device allocation, render, resolve, RGB8 copied to the host"}
         if world == 1 and not args.no_cpu:
-            cpu_and_roofline(out, args, cfg, bvh, scene, float(np.mean(kernel_ms)), total_rays, total_box, total_prim, bool(flags[-1] & 1))
+            cpu_and_roofline(out, args, cfg, bvh, scene, float(np.mean(kernel_ms)), total_rays, total_box, total_prim, bool(flags[-1] & 1), bool(flags[-1] & 2))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -247,7 +254,7 @@ def result_line(args, cfg, n_prims, n_gpus, elapsed, total_rays, total_box, tota
     }
 
 
-def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_box, total_prim, entries_in_lds):
+def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_box, total_prim, entries_in_lds, packed):
     """CPU baseline (the oracle timed on this box's cores on a bounded sample of the same frame) and the roofline of the
     dominant kernel from this run's own counts."""
     from oracle import binding as ob
@@ -257,20 +264,23 @@ def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_bo
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
     # event counts per sample (hits, shades, texture evaluations: the same events whoever traces the rays) from the
     # instrumented build on a 2-spp frame; the TIMED render uses the uninstrumented -O3 build
+    cw, ch = max(1, cfg.width // args.cpu_scale), max(1, cfg.height // args.cpu_scale)
+    print(f"[bench] CPU legs: {cw}x{ch}, counting events at 2 spp ...", file=sys.stderr, flush=True)
     ob.select("checker")
     ob.counters_reset()
-    ob.OracleCamera(cfg.replace(samples_per_pixel=2)).render(ob.OracleMesh(bvh), seed=args.seed, rng_kind=0, threads=cores, want_rgb=False)
+    ob.OracleCamera(cfg.replace(width=cw, height=ch, samples_per_pixel=2)).render(ob.OracleMesh(bvh), seed=args.seed, rng_kind=0, threads=cores, want_rgb=False)
     cnt = ob.counters()
+    print(f"[bench] timing the CPU baseline at {args.cpu_spp} spp on {cores} threads ...", file=sys.stderr, flush=True)
     ob.select("fast")
-    om, oc = ob.OracleMesh(bvh), ob.OracleCamera(cfg.replace(samples_per_pixel=args.cpu_spp))
+    om, oc = ob.OracleMesh(bvh), ob.OracleCamera(cfg.replace(width=cw, height=ch, samples_per_pixel=args.cpu_spp))
     t1 = time.perf_counter()
     oc.render(om, seed=args.seed, rng_kind=0, threads=cores, want_rgb=False)
     cpu_s = time.perf_counter() - t1
     ob.select("checker")
-    cpu_samples = cfg.width * cfg.height * args.cpu_spp
+    cpu_samples = cw * ch * args.cpu_spp
     out["cpu_baseline"] = {
         "value": round(cpu_samples / cpu_s / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"same scene and camera, {cfg.width}x{cfg.height} at {args.cpu_spp} spp ({cpu_samples / 1e6:.1f} Msamples, "
+        "sample": f"same scene and camera, {cw}x{ch} at {args.cpu_spp} spp ({cpu_samples / 1e6:.1f} Msamples, "
                   f"{cpu_s:.1f} s): C++ restatement of the reference CPU renderer (pointer-tree BVH, virtual dispatch, "
                   f"ChaCha12 + rejection samplers), not the Rust binary",
         "build": "g++ " + ob.BUILD_FLAGS["fast"],
@@ -293,9 +303,9 @@ def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_bo
     secs = kernel_ms * 1e-3
     own_tf = own_fps * samples_per_step / secs / 1e12
     ref_tf = ref_fps * samples_per_step / secs / 1e12
-    default_workload = (args.scene, args.seed, args.width, args.height, args.spp, args.depth, args.traversal, args.rr) == \
-        ("bouncing-spheres", 1, 1920, 1080, 1000, 50, "fast", 0)
-    traffic, traffic_file = measured_hbm_traffic(default_workload)
+    key = (args.scene, args.seed, args.width, args.height, args.spp, args.depth, args.traversal, args.rr, args.mesh_nlat)
+    tag = {("bouncing-spheres", 1, 1920, 1080, 1000, 50, "fast", 0, 0): "c2", ("triangle-mesh", 1, 1920, 1080, 256, 50, "fast", 0, 500): "c4"}.get(key)
+    traffic, traffic_file = measured_hbm_traffic(tag)
     valu = {"bound": "valu", "kernel": "render_kernel", "achieved": round(own_tf, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(own_tf / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_file, "kernel_ms": round(kernel_ms, 3),
             "algorithmic_flops_per_sample": round(own_fps, 1),
@@ -305,16 +315,31 @@ def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_bo
             "reference_work": {"flops_per_sample": round(ref_fps, 1), "achieved": round(ref_tf, 3), "frac": round(ref_tf / FP32_VECTOR_PEAK_TFLOPS, 4),
                                "note": "the same samples priced with the tests the REFERENCE performs (its origin-including boxes make its "
                                        "tree nearly useless): work delivered, which can exceed the peak because the kernel avoids it"}}
-    # entries beyond the LDS budget are walked from HBM / L2: node and primitive records fetched, 32 B per box, 32 B per
-    # sphere, 48 B per triangle / 68 B per quad
-    tri_like = scene.desc.n_tris > 0
-    rec_bytes = 32.0 if prim_events == 0 or cnt["quad_tests"] == 0 else (48.0 if tri_like else 68.0)
-    rec_bytes = (32.0 * cnt["sphere_tests"] + rec_bytes * cnt["quad_tests"]) / max(prim_events, 1)
-    gbs = (32.0 * total_box + rec_bytes * total_prim) / args.steps / secs / 1e9
+    # entries beyond the LDS budget are walked from HBM / L2.  Algorithmic bytes per test, as the kernel lays its data out:
+    #   packed array (no transforms / media):  box 16 B (six halfs + link), sphere 32 B, quad / triangle 80 B, all inline
+    #   32-byte entries otherwise:             box 32 B, sphere 32 B, quad / triangle 32 B entry + 80 B record
+    box_b, sph_b, planar_b = (16.0, 32.0, 80.0) if packed else (32.0, 32.0, 112.0)
+    rec_bytes = (sph_b * cnt["sphere_tests"] + planar_b * cnt["quad_tests"]) / max(prim_events, 1)
+    gbs = (box_b * total_box + rec_bytes * total_prim) / args.steps / secs / 1e9
     hbm = {"bound": "hbm", "kernel": "render_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-           "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "traffic": None, "kernel_ms": round(kernel_ms, 3),
-           "note": "algorithmic node + primitive record bytes of the kernel's own walk (32 B per box test, 32 / 48 / 68 B per sphere / "
-                   "triangle / quad test) per launch / kernel time"}
+           "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "traffic": traffic, "traffic_source": traffic_file, "kernel_ms": round(kernel_ms, 3),
+           "bytes_per_test": {"box": box_b, "primitive": round(rec_bytes, 1)},
+           "note": "algorithmic node + primitive bytes of the kernel's own walk (tests counted by the kernel in this run x the bytes "
+                   "one test reads) per launch / kernel time; most of these reads hit L2 or the Infinity Cache, so this is the "
+                   "walk's demand, not DRAM traffic"}
+    if args.work_counts:
+        with open(args.work_counts, "w") as f:
+            json.dump({
+                "workload": out["config"]["workload"],
+                "flops_per_event": FLOPS,
+                "oracle_events": {"note": "instrumented CPU restatement, reference-faithful mode, same fixture and seed, 2 spp", **{k: int(v) for k, v in cnt.items()}},
+                "kernel_run": {"note": "counted by render_kernel in the timed steps of this run", "steps": args.steps, "samples": int(n_samples),
+                               "rays": int(total_rays), "box_tests": int(total_box), "prim_tests": int(total_prim), "kernel_ms": round(kernel_ms, 3),
+                               "entries_in_lds": bool(entries_in_lds), "packed_array": bool(packed)},
+                "flops_per_sample": {"reference_work": round(ref_fps, 1), "own_walk": round(own_fps, 1)},
+                "bytes_per_test": {"box": box_b, "primitive": round(rec_bytes, 1)},
+            }, f, indent=1)
+            f.write("\n")
     if entries_in_lds:
         out["roofline"] = valu
     else:

@@ -238,7 +238,9 @@ typedef struct rtx_stats {
     double kernel_ms;     /* device time of the path-tracing kernel(s), HIP events on the launch stream */
     double total_ms;      /* wall time of the call */
     uint32_t n_launches;  /* launches of the dominant kernel */
-    uint32_t flags;       /* bit 0: the traversal entries were resident in LDS (small scene); else walked from HBM / L2 */
+    uint32_t flags;       /* bit 0: the traversal entries were resident in LDS (small scene); else walked from HBM / L2.
+                           * bit 1: the packed array was walked (16-byte slots: a box is 16 B in HBM, 32 B in LDS; a sphere 32 B;
+                           * a quad / triangle 80 B) instead of 32-byte entries with separate 80-byte planar records */
     uint64_t box_tests;   /* Aabb::hit evaluations the kernel performed (lanes x box steps), counted in the kernel */
     uint64_t prim_tests;  /* Sphere / Quad / triangle / bracket entries the kernel evaluated */
 } rtx_stats_t;

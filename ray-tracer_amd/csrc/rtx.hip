@@ -1493,7 +1493,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         stats->prim_tests = cnt[2];
         stats->kernel_ms = ms;
         stats->n_launches = 1;
-        stats->flags = in_lds ? 1u : 0u;
+        stats->flags = (in_lds ? 1u : 0u) | (pk ? 2u : 0u);
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 #ifdef RTX_STAGE_COUNTERS
         unsigned long long sc[12];
