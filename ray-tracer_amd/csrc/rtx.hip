@@ -42,9 +42,10 @@ static int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+constexpr uint32_t MAX_ITEM_SLOTS_HOST = 8;  // items in flight per wave, upper limit (render_kernel keeps one tile accumulator per slot in LDS)
 // Tuning knobs, read from the environment once per process.
 struct Knobs {
-    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, overlap, lds_ents_max, perlin_lds, waves_per_block,
+    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, perlin_lds, waves_per_block,
         blocks_per_cu, debug;
 };
 static const Knobs& knobs() {
@@ -61,7 +62,7 @@ static const Knobs& knobs() {
         x.w_prim = std::max(1u, u("RTX_W_PRIM", 8));
         x.w_serv = std::max(1u, u("RTX_W_SERV", 3));
         x.sched_kp = u("RTX_SCHED_KP", 32);
-        x.overlap = u("RTX_OVERLAP", 1);
+        x.item_slots = std::min(MAX_ITEM_SLOTS_HOST, std::max(1u, u("RTX_ITEM_SLOTS", 4)));
         x.lds_ents_max = u("RTX_LDS_ENTS_MAX", 72 * 1024);
         x.perlin_lds = u("RTX_PERLIN_LDS", 1);
         x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
@@ -682,7 +683,7 @@ struct RenderParams {
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
     uint32_t sched_kp;    // primitive stage keeps running while n_prim * sched_kp >= 8 * lanes queued elsewhere (0 = one step)
     uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
-    uint32_t overlap;     // 1: free lanes start on the wave's next item while the current one drains
+    uint32_t n_slots;     // items in flight per wave (tile accumulators per wave): 1 = no overlap of items
     uint32_t* item_counter;
     unsigned long long* ray_counter;  // [0] rays, [1] box tests, [2] primitive tests (then diagnostics)
     float* partial;       // [n_batches][H][W][3]
@@ -691,7 +692,8 @@ struct RenderParams {
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
 constexpr int MAX_WAVES_PER_BLOCK = 16;  // all waves of a block share one LDS copy of the entries; the launch picks 4, 8, 12 or 16
 constexpr int BLOCK_THREADS = 64 * MAX_WAVES_PER_BLOCK;
-constexpr int ACC_FLOATS = 64 * 3;   // one tile accumulator; every wave owns two (items A and B)
+constexpr int ACC_FLOATS = 64 * 3;   // one tile accumulator
+constexpr int SLOT_FLOATS = ACC_FLOATS + 4;  // LDS per item slot of a wave: the accumulator and a 16-byte header (all accumulators first)
 
 extern __shared__ uint4 smem[];
 
@@ -721,14 +723,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
 
     // LDS: [entries incl. terminator (optional)] [per-wave tile accumulators]
     const uint32_t ent_u4 = ENTS_IN_LDS ? (PK ? S.pk_slots : 2u * S.n_ents[M]) : 0u;
-    float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * (2 * ACC_FLOATS);
+    float* acc = reinterpret_cast<float*>(smem + ent_u4) + wave * (P.n_slots * SLOT_FLOATS);
     if (ENTS_IN_LDS) {
         for (uint32_t i = threadIdx.x; i < ent_u4; i += blockDim.x) smem[i] = gents[i];
     }
     // TEX: Perlin table set 0 (6 KB) behind the accumulators when the launch reserved room for it
     uint32_t lds_perlin = 0xFFFFFFFFu;
     if (TEX && P.perlin_in_lds != 0u) {
-        const uint32_t at_u4 = ent_u4 + (blockDim.x >> 6) * (2 * ACC_FLOATS / 4);
+        const uint32_t at_u4 = ent_u4 + (blockDim.x >> 6) * (P.n_slots * SLOT_FLOATS / 4);
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S.perlin);
         for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += blockDim.x) smem[at_u4 + i] = src[i];
         lds_perlin = at_u4 * 16u;
@@ -840,19 +842,21 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
         st = root_st;                    \
     } while (0)
 
-    // Two items are in flight per wave: A, whose pool is being drained, and B, which free lanes start on as soon as A's
-    // pool is empty.  Without the overlap every item would end with a drain phase in which most lanes sit idle.
-    struct ItemCtx {  // wave-uniform; kept small because it lives in scalar registers
-        uint32_t txy;         // tile origin: x | y << 16
-        uint32_t batch;       // which batch of sample indices
-        uint32_t pool_next;   // pool entry q = (sample q / 64, tile slot q % 64); slots outside the image are skipped
-        uint32_t pool_total;  // 0 = no item
-    };
-    ItemCtx A{}, B{};
-    uint32_t a_sel = 0;  // which half of the wave's accumulator A owns (B owns the other); a lane keeps it in slot bit 6
-    bool more = true;    // the global item counter may still have items
+    // Several items are in flight per wave (P.n_slots of them), each with a tile accumulator of its own.  One, `cur`, still
+    // has (pixel, sample) pairs in its pool: free lanes draw from it.  The others are draining: their pools are used up and
+    // their last paths are under way.  When cur's pool runs out, every item none of whose paths is still alive is written
+    // out and the next item is claimed into a free slot.  Without this an item would end with a drain phase in which most
+    // lanes sit idle; and with two slots only, one long path (fifty bounces, each a chain of dependent memory reads in a
+    // large scene) holds up every item behind it.
+    uint32_t cur = 0;                                           // slot of the item whose pool is being drawn from
+    uint32_t cur_txy = 0, cur_batch = 0;                        // its tile origin (x | y << 16) and batch of sample indices
+    uint32_t pool_next = 0, pool_total = 0;                     // pool entry q = (sample q / 64, tile slot q % 64)
+    uint32_t live = 0;                                          // bit k: slot k holds an item that has not been written out
+    bool more = true;                                           // the global item counter may still have items
+    const uint32_t n_slots = P.n_slots, all_slots = (1u << n_slots) - 1u;
+    uint32_t* const item_hdr = reinterpret_cast<uint32_t*>(acc + n_slots * ACC_FLOATS);  // [slot][4]: tile origin, batch
 
-#define RTX_CLAIM(ctx, sel)                                                                                      \
+#define RTX_CLAIM(k)                                                                                             \
     do {                                                                                                         \
         KArgs* q_ = RTX_ARGS();                                                                                  \
         uint32_t item_ = 0;                                                                                      \
@@ -862,57 +866,59 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
             more = false;                                                                                        \
         } else {                                                                                                 \
             const uint32_t tile_ = q_->tile_rank + (item_ % q_->n_owned) * q_->tile_world;                       \
-            ctx.batch = __builtin_amdgcn_readfirstlane(item_ / q_->n_owned);                                     \
-            ctx.txy = __builtin_amdgcn_readfirstlane(((tile_ % q_->tiles_x) * TILE) | (((tile_ / q_->tiles_x) * TILE) << 16)); \
-            ctx.pool_total = __builtin_amdgcn_readfirstlane(64u * min(q_->batch, q_->sample_end - (q_->sample_begin + ctx.batch * q_->batch))); \
-            ctx.pool_next = 0;                                                                                   \
-            acc[(sel) * ACC_FLOATS + lane] = 0.0f;                                                               \
-            acc[(sel) * ACC_FLOATS + lane + 64] = 0.0f;                                                          \
-            acc[(sel) * ACC_FLOATS + lane + 128] = 0.0f;                                                         \
+            cur = (k);                                                                                           \
+            live |= 1u << cur;                                                                                   \
+            cur_batch = __builtin_amdgcn_readfirstlane(item_ / q_->n_owned);                                     \
+            cur_txy = __builtin_amdgcn_readfirstlane(((tile_ % q_->tiles_x) * TILE) | (((tile_ / q_->tiles_x) * TILE) << 16)); \
+            pool_total = __builtin_amdgcn_readfirstlane(64u * min(q_->batch, q_->sample_end - (q_->sample_begin + cur_batch * q_->batch))); \
+            pool_next = 0;                                                                                       \
+            acc[cur * ACC_FLOATS + lane] = 0.0f;                                                                 \
+            acc[cur * ACC_FLOATS + lane + 64] = 0.0f;                                                            \
+            acc[cur * ACC_FLOATS + lane + 128] = 0.0f;                                                           \
+            if (lane == 0) {                                                                                     \
+                item_hdr[4u * cur] = cur_txy;                                                                    \
+                item_hdr[4u * cur + 1u] = cur_batch;                                                             \
+            }                                                                                                    \
         }                                                                                                        \
     } while (0)
 
-    RTX_CLAIM(A, a_sel);
-    if (A.pool_total != 0u) {
+    RTX_CLAIM(0u);
+    if (live != 0u) {
         for (;;) {
             const uint32_t n_box = (uint32_t)__popcll(__ballot(at_box(st)));
             const uint32_t n_done = (uint32_t)__popcll(__ballot(st == ENT_END));
             const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
             const uint32_t n_prim = 64u - n_box - n_done - n_idle;
-            bool a_has = A.pool_next < A.pool_total;
-            if (!a_has) {
-                // retire A once no lane carries one of its paths: write the tile's sums into this batch's partial image
-                // (each pixel of each batch has exactly one writer)
-                if (__ballot(st != ST_IDLE && (slot >> 6) == a_sel) == 0ull) {
+            if (pool_next >= pool_total) {
+                // write out the items no lane carries a path of: the tile's sums go into the batch's partial image (each
+                // pixel of each batch has exactly one writer)
+                const uint32_t my_item = st != ST_IDLE ? slot >> 6 : 0xFFFFFFFFu;
+                for (uint32_t k = 0; k < n_slots; k++) {
+                    if (((live >> k) & 1u) == 0u || __ballot(my_item == k) != 0ull) continue;
                     KArgs* Q = RTX_ARGS();
-                    const uint32_t a_tx = A.txy & 0xFFFFu, a_ty = A.txy >> 16;
-                    if (a_tx + (lane & 7u) < Q->cam.width && a_ty + (lane >> 3) < Q->cam.height) {
-                        const uint32_t px = a_tx + (lane & 7u), py = a_ty + (lane >> 3);
-                        float* dst = Q->partial + ((size_t)A.batch * Q->cam.height * Q->cam.width + (size_t)py * Q->cam.width + px) * 3;
-                        dst[0] = acc[a_sel * ACC_FLOATS + lane * 3 + 0];
-                        dst[1] = acc[a_sel * ACC_FLOATS + lane * 3 + 1];
-                        dst[2] = acc[a_sel * ACC_FLOATS + lane * 3 + 2];
+                    const uint32_t txy = __builtin_amdgcn_readfirstlane(item_hdr[4u * k]), batch = __builtin_amdgcn_readfirstlane(item_hdr[4u * k + 1u]);
+                    const uint32_t px = (txy & 0xFFFFu) + (lane & 7u), py = (txy >> 16) + (lane >> 3);
+                    if (px < Q->cam.width && py < Q->cam.height) {
+                        float* dst = Q->partial + ((size_t)batch * Q->cam.height * Q->cam.width + (size_t)py * Q->cam.width + px) * 3;
+                        dst[0] = acc[k * ACC_FLOATS + lane * 3 + 0];
+                        dst[1] = acc[k * ACC_FLOATS + lane * 3 + 1];
+                        dst[2] = acc[k * ACC_FLOATS + lane * 3 + 2];
                     }
-                    if ((wave_box | wave_prim) >= 0x40000000u) {  // keep the 32-bit tallies from wrapping on very long launches
-                        if (lane == 0) {
-                            atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
-                            atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
-                        }
-                        wave_box = 0;
-                        wave_prim = 0;
-                    }
-                    if (B.pool_total == 0u && more) RTX_CLAIM(B, a_sel ^ 1u);
-                    if (B.pool_total == 0u) break;  // nothing left anywhere
-                    A = B;
-                    B.pool_total = 0;
-                    a_sel ^= 1u;
-                    a_has = A.pool_next < A.pool_total;
-                } else if (B.pool_total == 0u && more && P.overlap != 0u) {
-                    RTX_CLAIM(B, a_sel ^ 1u);  // free lanes move on to the next item while A's last paths finish
+                    live &= ~(1u << k);
                 }
+                if ((wave_box | wave_prim) >= 0x40000000u) {  // keep the 32-bit tallies from wrapping on very long launches
+                    if (lane == 0) {
+                        KArgs* Q = RTX_ARGS();
+                        atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
+                        atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
+                    }
+                    wave_box = 0;
+                    wave_prim = 0;
+                }
+                if (more && live != all_slots) RTX_CLAIM((uint32_t)__builtin_ctz(~live));  // free lanes move on to the next item
+                if (live == 0u) break;  // nothing left anywhere
             }
-            const bool b_has = !a_has && B.pool_next < B.pool_total;
-            const uint32_t pool_left = a_has ? A.pool_total - A.pool_next : (b_has ? B.pool_total - B.pool_next : 0u);
+            const uint32_t pool_left = pool_total - min(pool_next, pool_total);
             const uint32_t n_serv = n_done + min(n_idle, pool_left);
             if (n_box + n_prim + n_serv == 0) continue;  // only possible while A drains a zero-depth pool
 #ifdef RTX_STAGE_COUNTERS
@@ -1151,16 +1157,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 //      (camera.rs:147-163)
                 const unsigned long long idle = __ballot(st == ST_IDLE);
                 if (idle && pool_left != 0u) {
-                    // all lanes of one pass draw from one item: A while its pool lasts, then B
-                    const uint32_t g_next = a_has ? A.pool_next : B.pool_next, g_total = a_has ? A.pool_total : B.pool_total;
-                    const uint32_t g_txy = a_has ? A.txy : B.txy, g_batch = a_has ? A.batch : B.batch;
-                    const uint32_t g_tx = g_txy & 0xFFFFu, g_ty = g_txy >> 16;
-                    const uint32_t g_s0 = Q->sample_begin + g_batch * Q->batch, g_sel = a_has ? a_sel : (a_sel ^ 1u);
-                    const uint32_t my = g_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    const uint32_t g_tx = cur_txy & 0xFFFFu, g_ty = cur_txy >> 16;
+                    const uint32_t g_s0 = Q->sample_begin + cur_batch * Q->batch;
+                    const uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                     const uint32_t my_slot = my & 63u;
                     const uint32_t x = g_tx + (my_slot & 7u), y = g_ty + (my_slot >> 3);
-                    if (st == ST_IDLE && my < g_total && x < C.width && y < C.height) {
-                        slot = my_slot | (g_sel << 6);
+                    if (st == ST_IDLE && my < pool_total && x < C.width && y < C.height) {
+                        slot = my_slot | (cur << 6);
                         const uint32_t sample = g_s0 + (my >> 6);
                         rng = rng_init(Q->seed0, Q->seed1, y * C.width + x, sample);
                         const float ox = rng_f32(rng) - 0.5f;
@@ -1188,8 +1191,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                         // ray_color(depth 0) is black before any hit test (camera.rs:125): the lane stays free
                         begin_walk = depth_left != 0;
                     }
-                    const uint32_t g_adv = __builtin_amdgcn_readfirstlane(min(g_total, g_next + (uint32_t)__popcll(idle)));
-                    if (a_has) A.pool_next = g_adv; else B.pool_next = g_adv;
+                    pool_next = __builtin_amdgcn_readfirstlane(min(pool_total, pool_next + (uint32_t)__popcll(idle)));
                 }
                 if (begin_walk) RTX_BEGIN_WALK();
                 RTX_TOC(2);
@@ -1214,7 +1216,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     __syncthreads();
     if (threadIdx.x < 3u) {
         unsigned long long sum = 0;
-        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) sum += reinterpret_cast<const unsigned long long*>(reinterpret_cast<float*>(smem + ent_u4) + w * (2 * ACC_FLOATS))[threadIdx.x];
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) sum += reinterpret_cast<const unsigned long long*>(reinterpret_cast<float*>(smem + ent_u4) + w * (P.n_slots * SLOT_FLOATS))[threadIdx.x];
         if (sum) atomicAdd(RTX_ARGS()->ray_counter + threadIdx.x, sum);
     }
 #ifdef RTX_STAGE_COUNTERS
@@ -1396,7 +1398,6 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     P.w_prim = K.w_prim;
     P.w_serv = K.w_serv;
     P.sched_kp = K.sched_kp;
-    P.overlap = K.overlap;
 
     const size_t need = npix3 * sizeof(float) * P.n_batches;
     if (scratch->partial_bytes < need) {  // only with may_grow
@@ -1444,25 +1445,31 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     const uint32_t vgprs = (uint32_t)std::max(fa.numRegs, 8);
     const uint32_t waves_per_simd = std::max(1u, std::min(8u, 512u / ((vgprs + 7u) & ~7u)));
     uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
-    size_t lds = 0;
+    const size_t slot_bytes = SLOT_FLOATS * sizeof(float);
     for (uint32_t b = 1; b <= (uint32_t)MAX_WAVES_PER_BLOCK / 4; b++) {
-        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * ACC_FLOATS * sizeof(float) + perlin_lds;
+        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * slot_bytes + perlin_lds;  // with two item slots per wave
         const uint32_t fit = (uint32_t)std::min<size_t>(waves_per_simd / b, (160 * 1024) / (l + 2048));
         if (fit * b >= best_resident && fit > 0) {
             best_resident = fit * b;
             wpb = 4 * b;
             blocks_per_cu = fit;
-            lds = l;
         }
     }
     if (best_resident == 0) return fail(RTX_ERR_DEVICE, "internal: no block shape fits");
     if (K.waves_per_block != 0u) wpb = std::min<uint32_t>(MAX_WAVES_PER_BLOCK, std::max<uint32_t>(4u, K.waves_per_block & ~3u));
     if (K.blocks_per_cu != 0u) blocks_per_cu = K.blocks_per_cu;
-    lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * 2 * ACC_FLOATS * sizeof(float) + perlin_lds;
+    // items in flight per wave: as many as the LDS left over by that shape holds, two at least
+    uint32_t n_slots = 2;
+    while (n_slots < K.item_slots &&
+           ((in_lds ? ent_bytes : 0) + (size_t)wpb * (n_slots + 1) * slot_bytes + perlin_lds + 2048) * blocks_per_cu <= 160 * 1024)
+        n_slots++;
+    if (K.item_slots < 2u) n_slots = K.item_slots;
+    P.n_slots = n_slots;
+    const size_t lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * n_slots * slot_bytes + perlin_lds;
     dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)c->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
     if (K.debug)
-        std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u batches of %u spp, %u items\n", vgprs, wpb,
-                     blocks_per_cu, lds, P.n_batches, P.batch, P.n_items);
+        std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u item slots/wave, %u batches of %u spp, %u items\n", vgprs, wpb,
+                     blocks_per_cu, lds, n_slots, P.n_batches, P.batch, P.n_items);
 
     if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
