@@ -1,18 +1,20 @@
 // librtx.so -- HIP kernels for gfx950 and the C ABI of include/rtx.h.
 //
 // Kernels
-//   trace_kernel    closest hit of arbitrary rays (the Mesh::hit contract); one lane per ray.
+//   trace_kernel, trace_packed_kernel   closest hit of arbitrary rays (the Mesh::hit contract); one lane per ray.
 //   render_kernel   Camera::render_pixel / ray_color as a persistent wavefront path tracer (see below).
 //   reduce_kernel   sums the per-batch partial images into the caller's accumulation buffer, in batch order.
 //   resolve_kernel  1/spp scale, sRGB transfer and 8-bit quantisation.
+//   add_slots_kernel, merge_tiles_kernel   combine the shares of several devices (rtx_render_multi).
 //
 // render_kernel.  Work is cut into items = (8x8 pixel tile, batch of sample indices).  Each 64-lane wave claims
 // items from a global counter and owns an item's pool of (pixel, sample) pairs: a lane that needs work takes the
-// next pair from the pool (ray generation), walks the threaded BVH held in LDS (extend), and when enough lanes of
-// the wave have finished their walk the wave shades them together (material evaluation, scatter), after which
-// finished paths are replaced from the pool in the same pass, so the wave's lanes stay compacted without any
-// queue in memory.  Radiance is added into the wave's tile accumulator in LDS and written once per item into a
-// per-batch partial image: no global atomics, and the result does not depend on how items were scheduled.
+// next pair from the pool (ray generation), walks the threaded BVH (extend; held in LDS when it fits), and when enough
+// lanes of the wave have finished their walk the wave shades them together (material evaluation, scatter), after
+// which finished paths are replaced from the pool in the same pass, so the wave's lanes stay compacted without any
+// queue in memory.  Radiance is added into the item's tile accumulator in LDS and written once per item into a
+// per-batch partial image: no global atomics.  Which samples a pixel gets and what each of them contributes does not
+// depend on how items were scheduled; the order in which the samples of one batch are added does (fp32 rounding only).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
