@@ -1568,6 +1568,17 @@ extern "C" int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t heig
     return RTX_OK;
 }
 
+template <class T>
+static int ensure_buffer(T** buf, size_t* have, size_t need) {
+    if (*have >= need) return RTX_OK;
+    if (*buf) hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc((void**)buf, need));
+    *have = need;
+    return RTX_OK;
+}
+
 extern "C" int rtx_render(rtx_scene_t* scene, const rtx_camera_t* cam, const rtx_render_opts_t* opts, uint8_t* rgb8_out, float* accum_out,
                           rtx_stats_t* stats) {
     if (!scene || !opts || !rgb8_out) return fail(RTX_ERR_INVALID, "null argument");
@@ -1575,34 +1586,22 @@ extern "C" int rtx_render(rtx_scene_t* scene, const rtx_camera_t* cam, const rtx
     int rc = check_camera(cam);
     if (rc != RTX_OK) return rc;
     auto t_start = std::chrono::steady_clock::now();
-    HIP_TRY(hipSetDevice(scene->primary.device));
+    DeviceCopy* c = &scene->primary;
+    HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)cam->width * cam->height * 3;
-    float* accum = nullptr;
-    uint8_t* rgb = nullptr;
-    HIP_TRY(hipMalloc((void**)&accum, n * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&rgb, n);
-    if (e != hipSuccess) {
-        hipFree(accum);
-        return fail(RTX_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
-    }
+    // the frame's device buffers stay with the scene: a small frame costs less to render than two allocations
+    if ((rc = ensure_buffer(&c->accum, &c->accum_bytes, n * sizeof(float))) != RTX_OK) return rc;
+    if ((rc = ensure_buffer(&c->rgb, &c->rgb_bytes, n)) != RTX_OK) return rc;
     rtx_render_opts_t o = *opts;
     if (o.sample_begin == 0 && o.sample_end == 0) o.sample_end = cam->samples_per_pixel;
     rtx_stats_t local;
     std::memset(&local, 0, sizeof(local));
-    e = hipMemset(accum, 0, n * sizeof(float));
-    if (e == hipSuccess) {
-        rc = rtx_render_accumulate(scene, cam, &o, accum, nullptr, &local);
-        if (rc == RTX_OK) rc = rtx_resolve(accum, cam->width, cam->height, cam->pixel_samples_scale, rgb, nullptr);
-        if (rc == RTX_OK) {
-            e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemcpy(rgb8_out, rgb, n, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && accum_out) e = hipMemcpy(accum_out, accum, n * sizeof(float), hipMemcpyDeviceToHost);
-        }
-    }
-    hipFree(accum);
-    hipFree(rgb);
+    HIP_TRY(hipMemsetAsync(c->accum, 0, n * sizeof(float), nullptr));
+    rc = rtx_render_accumulate(scene, cam, &o, c->accum, nullptr, stats ? &local : nullptr);  // (reading the timers costs a synchronise)
+    if (rc == RTX_OK) rc = rtx_resolve(c->accum, cam->width, cam->height, cam->pixel_samples_scale, c->rgb, nullptr);
     if (rc != RTX_OK) return rc;
-    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(rgb8_out, c->rgb, n, hipMemcpyDeviceToHost));  // (waits for the null stream)
+    if (accum_out) HIP_TRY(hipMemcpy(accum_out, c->accum, n * sizeof(float), hipMemcpyDeviceToHost));
     if (stats) {
         *stats = local;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -1682,17 +1681,6 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
     HIP_TRY(hipMalloc((void**)&r->counters, COUNTER_BYTES));
     HIP_TRY(hipEventCreate(&r->ev0));
     HIP_TRY(hipEventCreate(&r->ev1));
-    return RTX_OK;
-}
-
-template <class T>
-static int ensure_buffer(T** buf, size_t* have, size_t need) {
-    if (*have >= need) return RTX_OK;
-    if (*buf) hipFree(*buf);
-    *buf = nullptr;
-    *have = 0;
-    HIP_TRY(hipMalloc((void**)buf, need));
-    *have = need;
     return RTX_OK;
 }
 
