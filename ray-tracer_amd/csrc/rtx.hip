@@ -1372,11 +1372,13 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     // balance the tail of the launch, but an item shorter than ~20 samples per pixel spends too much of its life
     // filling and draining.  Between 4 and 64 items per wave, as many as keep a batch at 20 samples or more.
     const uint32_t waves = (uint32_t)c->n_cus * 32u;
+    const uint32_t tile_world = std::max<uint32_t>(1u, opts->tile_world);
+    const uint32_t my_tiles = std::max<uint32_t>(1u, (n_tiles + tile_world - 1) / tile_world);  // (about) the tiles this call owns
     uint32_t n_batches;
     if (K.items_per_wave != 0u) {
-        n_batches = (waves * K.items_per_wave + n_tiles - 1) / n_tiles;
+        n_batches = (waves * K.items_per_wave + my_tiles - 1) / my_tiles;
     } else {
-        const uint32_t lo = (waves * 4u + n_tiles - 1) / n_tiles, hi = (waves * 64u + n_tiles - 1) / n_tiles;
+        const uint32_t lo = (waves * 4u + my_tiles - 1) / my_tiles, hi = (waves * 64u + my_tiles - 1) / my_tiles;
         n_batches = std::min(hi, std::max(lo, spp / 20u));
     }
     n_batches = std::min<uint32_t>(spp, std::max<uint32_t>(1u, n_batches));
