@@ -888,9 +888,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
     if (live != 0u) {
         for (;;) {
             const uint32_t n_box = (uint32_t)__popcll(__ballot(at_box(st)));
-            const uint32_t n_done = (uint32_t)__popcll(__ballot(st == ENT_END));
-            const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
-            const uint32_t n_prim = 64u - n_box - n_done - n_idle;
+            // finished walks and free lanes: the two largest state words, one compare for both
+            static_assert(ENT_END == 0xFFFFFFFEu && ST_IDLE == 0xFFFFFFFFu, "done and idle are the two largest state words");
+            const uint32_t n_rest = (uint32_t)__popcll(__ballot(st >= ENT_END));
+            const uint32_t n_prim = 64u - n_box - n_rest;
             if (pool_next >= pool_total) {
                 // write out the items no lane carries a path of: the tile's sums go into the batch's partial image (each
                 // pixel of each batch has exactly one writer)
@@ -921,7 +922,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 if (live == 0u) break;  // nothing left anywhere
             }
             const uint32_t pool_left = pool_total - min(pool_next, pool_total);
-            const uint32_t n_serv = n_done + min(n_idle, pool_left);
+            // lanes the service stage has work for: every finished walk, and as many free lanes as the pool has pairs for
+            // (the free lanes are counted only when the pool is nearly empty)
+            uint32_t n_serv = n_rest;
+            if (pool_left < 64u) {
+                const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
+                n_serv = n_rest - n_idle + min(n_idle, pool_left);
+            }
             if (n_box + n_prim + n_serv == 0) continue;  // only possible while A drains a zero-depth pool
 #ifdef RTX_STAGE_COUNTERS
             sc[7]++;
@@ -1036,8 +1043,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 RTX_TIC();
 #ifdef RTX_STAGE_COUNTERS
                 sc[4]++;
-                sc[5] += n_done;
-                sc[6] += min(n_idle, pool_left);
+                sc[5] += (uint32_t)__popcll(__ballot(st == ENT_END));
+                sc[6] += n_serv - (uint32_t)__popcll(__ballot(st == ENT_END));
 #endif
                 KArgs* Q = RTX_ARGS();
                 __attribute__((address_space(4))) const rtx_camera_t& C = Q->cam;
