@@ -921,7 +921,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                 if (more && live != all_slots) RTX_CLAIM((uint32_t)__builtin_ctz(~live));  // free lanes move on to the next item
                 if (live == 0u) break;  // nothing left anywhere
             }
-            const uint32_t pool_left = pool_total - min(pool_next, pool_total);
+            const uint32_t pool_left = pool_total - pool_next;  // (pool_next never passes pool_total)
             // lanes the service stage has work for: every finished walk, and as many free lanes as the pool has pairs for
             // (the free lanes are counted only when the pool is nearly empty)
             uint32_t n_serv = n_rest;
@@ -948,7 +948,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                     constexpr uint32_t BOX_BYTES = ENTS_IN_LDS ? 2u * PK_SLOT : PK_SLOT;
                     const uint32_t k1 = P.sched_k + 1u;
                     bool here = at_box(st);
-                    uint4 e = make_uint4(0, 0, 0, 0), e1 = e;
+                    // lanes that are not at a box never read e / e1: leave their registers as they are instead of clearing them
+                    uint4 e, e1;
+                    asm("" : "=v"(e.x), "=v"(e.y), "=v"(e.z), "=v"(e.w), "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w));
                     if (here) {
                         RTX_LOAD_SLOT(off, e);
                         if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
@@ -972,7 +974,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_ker
                     } while (nb * k1 >= n_fixed && nb > 0);
                     wave_box += tests;
                 } else {
-                    uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
+                    uint4 ea, eb;  // (as above: only lanes at a box read them)
+                    asm("" : "=v"(ea.x), "=v"(ea.y), "=v"(ea.z), "=v"(ea.w), "=v"(eb.x), "=v"(eb.y), "=v"(eb.z), "=v"(eb.w));
                     if (st == ENT_BOX) RTX_LOAD_ENTRY(off, ea, eb);
                     do {
                         wave_box += nb;
