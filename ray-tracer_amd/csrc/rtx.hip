@@ -710,7 +710,10 @@ extern __shared__ uint4 smem[];
 // PK: walk the packed form of the fast array (16-byte slots, half-precision boxes) instead of the 32-byte entries; only
 // for the fast walk of scenes without brackets (!STRICT && !XF).
 template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false>
-__global__ __launch_bounds__(BLOCK_THREADS, (XF || TEX) ? 4 : 8) void render_kernel(RenderParams P) {
+// Registers per variant, through the waves per SIMD the compiler must leave room for: the lean variants 64 (8 waves), the
+// bracket variants 96 (5 waves: +10 % over 4 on the Cornell scenes, three spilled registers; at 6 they spill 47 and lose
+// 20 %), the texture variants end up at 95 on their own.
+__global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) void render_kernel(RenderParams P) {
     static_assert(!PK || (!STRICT && !XF), "the packed array exists for the fast walk of bracket-free scenes only");
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;

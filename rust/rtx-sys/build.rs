@@ -16,7 +16,7 @@ fn main() {
     }
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
     let status = Command::new(hipcc)
-        .args(["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"])
+        .args(["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-fPIC", "-shared"])
         .arg(format!("-I{}", root.join("include").display()))
         .arg(&src)
         .arg("-o")
