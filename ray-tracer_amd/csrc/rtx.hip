@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                         RTX_LOAD_STATE(off, st);
                     }
                     np = (uint32_t)__popcll(__ballot(at_prim(st)));
-                } while (XF && np * P.sched_kp >= 8u * (n_fixed - np) && np > 0);  // in the lean variant the loop would cost registers, i.e. a resident wave
+                } while ((XF || (PK && !ENTS_IN_LDS)) && np * (XF ? P.sched_kp : 8u * P.sched_kp) >= 8u * (n_fixed - np) && np > 0);  // (small scenes: one step, the loop is not worth its code;
+                  // leaves of a large mesh put up to four triangles in a row, and every pass through the scheduler waits for a state word from HBM: +2.5 %)
                 RTX_TOC(1);
             } else {
                 // ---- service stage 1, shade: camera.rs:127-142 for every lane whose walk is complete
