@@ -47,7 +47,7 @@ static int fail(int code, const std::string& msg) {
 constexpr uint32_t MAX_ITEM_SLOTS_HOST = 8;  // items in flight per wave, upper limit (render_kernel keeps one tile accumulator per slot in LDS)
 // Tuning knobs, read from the environment once per process.
 struct Knobs {
-    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, perlin_lds, waves_per_block,
+    uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, planar_lds_max, perlin_lds, waves_per_block,
         blocks_per_cu, debug;
 };
 static const Knobs& knobs() {
@@ -67,6 +67,7 @@ static const Knobs& knobs() {
         x.item_slots = std::min(MAX_ITEM_SLOTS_HOST, std::max(1u, u("RTX_ITEM_SLOTS", 4)));
         x.lds_ents_max = u("RTX_LDS_ENTS_MAX", 72 * 1024);
         x.perlin_lds = u("RTX_PERLIN_LDS", 1);
+        x.planar_lds_max = u("RTX_PLANAR_LDS_MAX", 16 * 1024);
         x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
         x.blocks_per_cu = u("RTX_BLOCKS_PER_CU", 0);
         x.debug = u("RTX_DEBUG", 0);
@@ -126,6 +127,7 @@ struct rtx_scene {
     bool pk_half = false;  // boxes of the packed array in half precision (arrays too large for LDS)
     uint32_t pk_slots = 0;
     uint32_t n_quads = 0;
+    uint32_t n_planar = 0;  // quads + triangles (80-byte records)
     std::vector<float4> planar_host;      // 5 per quad / triangle, as uploaded
     std::vector<uint32_t> planar_id_host;
 };
@@ -423,6 +425,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     if ((rc = upload(dc, planar_id, &dc->dev.planar_id)) != RTX_OK) return rc;
     dc->dev.n_quads = d->n_quads;
     s->n_quads = d->n_quads;
+    s->n_planar = d->n_quads + d->n_tris;
     if ((rc = upload(dc, s->mat_recs, &dc->dev.mat_recs)) != RTX_OK) return rc;
     {
         // the packed form of the fast array, which the render kernels walk when the scene has no brackets
@@ -685,6 +688,7 @@ struct RenderParams {
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
     uint32_t sched_kp;    // primitive stage keeps running while n_prim * sched_kp >= 8 * lanes queued elsewhere (0 = one step)
     uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
+    uint32_t planar_in_lds;  // quad / triangle records (80 bytes each) the launch reserved LDS for, behind the Perlin tables: all of them or 0
     uint32_t n_slots;     // items in flight per wave (tile accumulators per wave): 1 = no overlap of items
     uint32_t* item_counter;
     unsigned long long* ray_counter;  // [0] rays, [1] box tests, [2] primitive tests (then diagnostics)
@@ -740,7 +744,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
         for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += blockDim.x) smem[at_u4 + i] = src[i];
         lds_perlin = at_u4 * 16u;
     }
-    if (ENTS_IN_LDS || TEX) __syncthreads();
+    // Unpacked variants: the quad / triangle records go to LDS as well when they are few (a Cornell box: 18), so that a
+    // primitive step does not wait twice for global memory (plane first, edges after the range check).
+    const float4* planar_recs = S.planar;
+    if (!PK && P.planar_in_lds != 0u) {
+        const uint32_t at_u4 = ent_u4 + (blockDim.x >> 6) * (P.n_slots * SLOT_FLOATS / 4) + (TEX && P.perlin_in_lds != 0u ? 1536u / 4u : 0u);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(S.planar);
+        for (uint32_t i = threadIdx.x; i < 5u * P.planar_in_lds; i += blockDim.x) smem[at_u4 + i] = src[i];
+        planar_recs = reinterpret_cast<const float4*>(smem + at_u4);
+    }
+    __syncthreads();
 
     // The kernel arguments once more, as they lie in the kernarg segment.  Values the walk loops need (scheduler
     // constants, a pointer or two) are read from P and stay in scalar registers; everything a stage needs only when it
@@ -1034,7 +1047,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                             } else {
                                 const uint32_t pi = eb.w >> 4;
                                 const bool tri = kind == ENT_TRI;
-                                planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                                planar_test<STRICT>(planar_recs, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
                             }
                             if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
                             off += ENT_BYTES;
@@ -1455,6 +1468,9 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     // noise textures read their tables 336 times per value: table set 0 goes to LDS (6 KB per block)
     const size_t perlin_lds = scene->has_tex && scene->n_perlins != 0 && K.perlin_lds != 0u ? 1536 * sizeof(float) : 0;
     P.perlin_in_lds = perlin_lds != 0 ? 1u : 0u;
+    // unpacked arrays in LDS: up to 16 KB of quad / triangle records follow them
+    const size_t planar_lds = (!pk && in_lds && scene->n_planar != 0 && (size_t)scene->n_planar * 80 <= K.planar_lds_max) ? (size_t)scene->n_planar * 80 : 0;
+    P.planar_in_lds = planar_lds != 0 ? scene->n_planar : 0u;
     // Block shape: a block is 4, 8, 12 or 16 waves (1 to 4 per SIMD).  The variant's register count says how many waves a
     // SIMD can hold (512 VGPRs each, allocated in eights); take the shape that makes the most waves resident within
     // the 160 KB of LDS, and on a tie the larger block (fewer LDS copies of the entries).
@@ -1465,7 +1481,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
     const size_t slot_bytes = SLOT_FLOATS * sizeof(float);
     for (uint32_t b = 1; b <= (uint32_t)MAX_WAVES_PER_BLOCK / 4; b++) {
-        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * slot_bytes + perlin_lds;  // with two item slots per wave
+        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * slot_bytes + perlin_lds + planar_lds;  // with two item slots per wave
         const uint32_t fit = (uint32_t)std::min<size_t>(waves_per_simd / b, (160 * 1024) / (l + 2048));
         if (fit * b >= best_resident && fit > 0) {
             best_resident = fit * b;
@@ -1479,11 +1495,11 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     // items in flight per wave: as many as the LDS left over by that shape holds, two at least
     uint32_t n_slots = 2;
     while (n_slots < K.item_slots &&
-           ((in_lds ? ent_bytes : 0) + (size_t)wpb * (n_slots + 1) * slot_bytes + perlin_lds + 2048) * blocks_per_cu <= 160 * 1024)
+           ((in_lds ? ent_bytes : 0) + (size_t)wpb * (n_slots + 1) * slot_bytes + perlin_lds + planar_lds + 2048) * blocks_per_cu <= 160 * 1024)
         n_slots++;
     if (K.item_slots < 2u) n_slots = K.item_slots;
     P.n_slots = n_slots;
-    const size_t lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * n_slots * slot_bytes + perlin_lds;
+    const size_t lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * n_slots * slot_bytes + perlin_lds + planar_lds;
     dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)c->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
     if (K.debug)
         std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u item slots/wave, %u batches of %u spp, %u items\n", vgprs, wpb,
