@@ -1043,11 +1043,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                             bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
                         } else {
                             if (kind == ENT_SPHERE) {
-                                sphere_test<STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);
+                                sphere_test<STRICT, 5, !STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);  // (fast walk: roots through the hardware square root / reciprocal)
                             } else {
                                 const uint32_t pi = eb.w >> 4;
                                 const bool tri = kind == ENT_TRI;
-                                planar_test<STRICT>(planar_recs, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                                planar_test<STRICT, !STRICT>(planar_recs, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
                             }
                             if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
                             off += ENT_BYTES;

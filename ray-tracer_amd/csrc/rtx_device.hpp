@@ -269,13 +269,16 @@ __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, co
 
 // Quad::hit (mesh.rs:202-221, :248-256); TRI uses the same plane / alpha / beta with the triangle's domain.
 // LD(k) returns record k of the primitive: 0 (Q.xyz, d)  1 (u.xyz, ..)  2 (v.xyz, ..)  3 (n.xyz, ..)  4 (w.xyz, ..).
-template <bool STRICT, int SHIFT, class LD>
+// QUICK (render kernels' fast walk only): the division through the hardware reciprocal.
+template <bool STRICT, int SHIFT, bool QUICK = false, class LD>
 __device__ __forceinline__ void planar_test_ld(LD ld, bool is_tri, const Ray& r, float tmin, Best& best, uint32_t idx,
                                                const uint32_t* __restrict__ rank) {
+    static_assert(!(STRICT && QUICK), "the strict walk reproduces the reference's arithmetic");
     const float4 q = ld(0), n = ld(3);
     float denom = dot3(n.x, n.y, n.z, r.dx, r.dy, r.dz);
     if (fabsf(denom) < 1e-8f) return;
-    float t = (q.w - dot3(n.x, n.y, n.z, r.ox, r.oy, r.oz)) / denom;
+    const float num = q.w - dot3(n.x, n.y, n.z, r.ox, r.oy, r.oz);
+    float t = QUICK ? num * __builtin_amdgcn_rcpf(denom) : num / denom;
     if (!in_range<STRICT, SHIFT>(t, tmin, best, idx, rank)) return;
     const float4 u = ld(1), v = ld(2), w = ld(4);
     float px = (r.ox + r.dx * t) - q.x, py = (r.oy + r.dy * t) - q.y, pz = (r.oz + r.dz * t) - q.z;
@@ -288,10 +291,10 @@ __device__ __forceinline__ void planar_test_ld(LD ld, bool is_tri, const Ray& r,
     best.t = t;
     best.ent = idx;
 }
-template <bool STRICT>
+template <bool STRICT, bool QUICK = false>
 __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, uint32_t pidx, bool is_tri, const Ray& r, float tmin, Best& best,
                                             uint32_t idx, const uint32_t* __restrict__ rank) {
-    planar_test_ld<STRICT, 5>([&](int k) { return planar[5 * pidx + k]; }, is_tri, r, tmin, best, idx, rank);
+    planar_test_ld<STRICT, 5, QUICK>([&](int k) { return planar[5 * pidx + k]; }, is_tri, r, tmin, best, idx, rank);
 }
 
 // One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
@@ -468,7 +471,7 @@ __device__ __forceinline__ uint32_t pk_prim_test(const uint4& s0, const uint4& s
         return 2u * PK_SLOT;
     }
     // slots (n, tag) (Q, d) (u, material) (v, prim id) (w, 0) -> records 0 Q  1 u  2 v  3 n  4 w
-    planar_test_ld<false, 4>(
+    planar_test_ld<false, 4, QUICK>(
         [&](int k) { return k == 0 ? as_f4(s1) : k == 3 ? as_f4(s0) : as_f4(ld(k == 4 ? 4 : k + 1)); }, kind == ENT_TRI, r, tmin, best, off, rank);
     return 5u * PK_SLOT;
 }

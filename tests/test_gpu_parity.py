@@ -310,8 +310,8 @@ def test_viewpoint_ordering_keeps_every_hit(render, oracle, scenes, name, seed):
 @pytest.mark.parametrize("name,seed", [("bouncing-spheres", 1), ("quads", 0), ("earth", 0), ("simple-light", 1), ("cornell-box", 0)])
 def test_strict_and_fast_render_agree(render, scenes, name, seed):
     """Same seed, both traversal modes.  The fast walk tests other boxes but finds the same hits; in the render kernels it
-    also takes a sphere's roots through the hardware square root and reciprocal, so a hit distance can differ from the
-    strict walk's by a few ulps.  Paths are chaotic (a bounce off a small sphere magnifies a deviation), so a small
+    also takes a sphere's roots and a quad's plane distance through the hardware square root and reciprocal, so a hit
+    distance can differ from the strict walk's by a few ulps.  Paths are chaotic (a bounce off a small sphere magnifies a deviation), so a small
     share of the samples ends elsewhere: most pixel values are identical, nearly all agree to 1e-4, and the frames'
     means agree.  quads, earth and simple-light look at the scene from outside its own coordinate range: the fast
     boxes are enlarged for that distance instead of falling back to the strict walk."""
