@@ -198,12 +198,21 @@ typedef struct rtx_hit {
 enum {
     RTX_TRAVERSAL_FAST = 0,  /* library-built SAH BVH over tight boxes, closest hit with the reference's tie-break */
     RTX_TRAVERSAL_STRICT = 1, /* walks bvh_nodes exactly as Bvh::hit does (mesh.rs:608-620), same boxes, same order */
-    RTX_TRAVERSAL_FAST_FUSED = 2 /* rtx_trace / rtx_traversal_dump only: the fast data exactly as the render kernels walk
+    RTX_TRAVERSAL_FAST_FUSED = 2, /* rtx_trace / rtx_traversal_dump only: the fast data exactly as the render kernels walk
                                     it -- the packed form (16-byte slots, half-precision boxes in centre / half-extent
                                     form) when the scene has no Translate / RotateY / ConstantMedium, else the 32-byte
                                     entries -- with their box test (fused multiply-adds, hardware reciprocal).  Same
                                     hits as FAST for ray origins inside the scene's coordinate range or, after a
                                     render, within the reach of that render's camera: the boxes are padded for that. */
+    RTX_TRAVERSAL_RENDER = 3 /* rtx_trace only: every step of the walk through the very functions the kernel of a
+                                    RTX_TRAVERSAL_FAST render of this scene calls -- FAST_FUSED's data, and on top of its
+                                    box test: ray parameters scaled by 2^-60 with the interval start clamped to 0 (float
+                                    boxes), sphere roots and plane distances through the hardware square root and
+                                    reciprocal, normals multiplied by a reciprocal radius.  Hit distances, points and
+                                    normals agree with FAST to a few units in the last place (not bit for bit), ids
+                                    except where two primitives lie within that distance of each other.  It exists so
+                                    that the arithmetic the benchmark times can be checked ray by ray against the
+                                    reference's Sphere::hit / Quad::hit (mesh.rs:113-139, :202-221). */
 };
 
 typedef struct rtx_trace_opts {

@@ -526,7 +526,8 @@ static uint32_t seed_word(uint64_t seed, int which) {  // the two 32-bit words t
 }
 
 // ================================================================================================ trace
-template <bool STRICT, int SLAB>
+// QUICK: primitive tests and hit record as the render kernels' fast walk evaluates them (RTX_TRAVERSAL_RENDER).
+template <bool STRICT, int SLAB, bool QUICK = false>
 __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax, uint32_t seed0,
                                                     uint32_t seed1, rtx_hit_t* __restrict__ hits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
             bracket_step<STRICT, SLAB>(reader, ea, eb, off, r, rc, wray, best, x, tmin, rng, rank);
         } else {
             const uint32_t at = off;
-            off = walk_step<STRICT, SLAB>(S, ea, eb, off, r, rc, x.tmin, best, rank);
+            off = walk_step<STRICT, SLAB, QUICK>(S, ea, eb, off, r, rc, x.tmin, best, rank);
             if (best.ent == at) x.best_xf = x.cur_xf;
         }
     }
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
         out.front_face = 0;
         out.p[0] = out.p[1] = out.p[2] = 0.0f;
     } else {
-        HitRec h = make_hit_x<true, true>(S, reader, wray, best, x.best_xf);
+        HitRec h = make_hit_x<true, !QUICK>(S, reader, wray, best, x.best_xf);
         out.prim_id = h.prim_id;
         out.t = best.t;
         out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
@@ -581,8 +582,14 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
 }
 
 // The same contract over the packed form of the fast array, with the box test the render kernels use.
+// RENDER = false: exact roots and hit record on top of the fused box test (RTX_TRAVERSAL_FAST_FUSED).
+// RENDER = true : every step through the functions render_kernel<..., PK> itself calls -- the scaled, clamped box test on
+//                 float boxes (SCALED) or the half-precision box test, hardware square root / reciprocal in the primitive
+//                 tests, reciprocal-multiplied normals (RTX_TRAVERSAL_RENDER).
+template <bool RENDER, bool SCALED>
 __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
                                                             rtx_hit_t* __restrict__ hits) {
+    static_assert(RENDER || !SCALED, "only the render walk runs in scaled ray parameters");
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const SlotReader slots{S.pk};
@@ -591,20 +598,29 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
     r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
     r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
     r.time = rays[i].time;
-    const RayConst rc = ray_const<SLAB_FMA>(r);
+    RayConst rc = ray_const<SLAB_FMA>(r);
+    if (SCALED) scale_ray_const(rc);
     Best best;
-    best.t = tmax;
+    best.t = SCALED ? tmax * PK_T_SCALE : tmax;
     best.ent = NO_HIT;
     uint32_t off = 0;
     for (;;) {
         const uint4 e = slots.at(off);
         if (e.w == ENT_END) break;
         if (e.w < PK_PRIM) {
-            const bool hit = S.pk_half ? pk_slab_hit(e, rc, tmin, best.t) : pk_slab_hit(e, slots.at(off + PK_SLOT), rc, tmin, best.t);
+            bool hit;
+            if (RENDER)
+                hit = pk_render_box<SCALED>(e, SCALED ? slots.at(off + PK_SLOT) : e, rc, tmin, best.t);
+            else
+                hit = S.pk_half ? pk_slab_hit(e, rc, tmin, best.t) : pk_slab_hit(e, slots.at(off + PK_SLOT), rc, tmin, best.t);
             off = hit ? off + (S.pk_half ? PK_SLOT : 2u * PK_SLOT) : (S.pk_half ? e.w * PK_SLOT : e.w);  // float boxes carry byte links
         } else {
             const uint32_t at = off;
-            off += pk_prim_test<false>(e, slots.at(off + PK_SLOT), [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); }, off, r, rc, tmin, best, rank);
+            const auto slot_at = [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); };
+            if (RENDER)
+                off += pk_render_prim<SCALED>(e, slots.at(off + PK_SLOT), slot_at, off, r, rc, tmin, best, rank);
+            else
+                off += pk_prim_test<false>(e, slots.at(off + PK_SLOT), slot_at, off, r, rc, tmin, best, rank);
         }
     }
     rtx_hit_t out;
@@ -612,7 +628,9 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
     out.prim_id = RTX_MISS;
     if (best.ent != NO_HIT) {
         const uint32_t at = best.ent;
-        HitRec h = pk_make_hit<true, true, true>(S, [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); }, r, best.t);
+        const auto slot_at = [&](int k) { return slots.at(at + (uint32_t)k * PK_SLOT); };
+        const HitRec h = RENDER ? pk_render_hit<SCALED, true, true>(S, slot_at, r, best.t) : pk_make_hit<true, true, true>(S, slot_at, r, best.t);
+        if (SCALED) best.t *= PK_T_UNSCALE;
         out.prim_id = h.prim_id;
         out.t = best.t;
         out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
 extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
                                 void* stream) {
     if (!scene || !opts || (n && (!rays_dev || !hits_dev))) return fail(RTX_ERR_INVALID, "null argument");
-    if (opts->traversal > RTX_TRAVERSAL_FAST_FUSED) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    if (opts->traversal > RTX_TRAVERSAL_RENDER) return fail(RTX_ERR_INVALID, "unknown traversal mode");
     if (n == 0) return RTX_OK;
     if (n > ((size_t)1 << 39)) return fail(RTX_ERR_INVALID, "too many rays for one call");
     hipStream_t st = (hipStream_t)stream;
@@ -636,10 +654,17 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
         hipLaunchKernelGGL((trace_kernel<true, SLAB_STRICT>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST)
         hipLaunchKernelGGL((trace_kernel<false, SLAB_ROBUST>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
-    else if (scene->packed)  // what the render kernels walk for this scene
-        hipLaunchKernelGGL(trace_packed_kernel, grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
-    else
+    else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->packed)  // what the render kernels walk for this scene
+        hipLaunchKernelGGL((trace_packed_kernel<false, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED)
         hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+    // RTX_TRAVERSAL_RENDER: the walk of the render kernel variant a fast render of this scene launches
+    else if (scene->packed && !scene->pk_half)  // render_kernel<false, true, false, *, true>: float boxes, scaled ray parameters
+        hipLaunchKernelGGL((trace_packed_kernel<true, true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    else if (scene->packed)  // render_kernel<false, false, false, *, true>: half-precision boxes
+        hipLaunchKernelGGL((trace_packed_kernel<true, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    else  // render_kernel<false, *, *, *, false>: 32-byte entries (scenes with Translate / RotateY / ConstantMedium)
+        hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA, true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
 }
@@ -979,7 +1004,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                         sc[1] += nb;
 #endif
                         if (here) {
-                            const bool hit = ENTS_IN_LDS ? pk_slab_hit_scaled(e, e1, rc, best.t) : pk_slab_hit(e, rc, tmin, best.t);
+                            const bool hit = pk_render_box<SCALED>(e, e1, rc, tmin, best.t);
                             off = hit ? off + BOX_BYTES : (ENTS_IN_LDS ? st : st * PK_SLOT);  // float boxes carry byte links
                             RTX_LOAD_SLOT(off, e);
                             if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
@@ -1026,11 +1051,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                             uint4 s0, s1;
                             RTX_LOAD_SLOT(off, s0);
                             RTX_LOAD_SLOT(off + PK_SLOT, s1);
-                            Best real = best;  // the primitive tests work in the ray's own parameter
-                            if (SCALED) real.t = best.t * PK_T_UNSCALE;
-                            off += pk_prim_test<true>(s0, s1, slot_of(off), off, ray, rc, tmin, real, rank);
-                            best.ent = real.ent;
-                            best.t = SCALED ? real.t * PK_T_SCALE : real.t;
+                            off += pk_render_prim<SCALED>(s0, s1, slot_of(off), off, ray, rc, tmin, best, rank);
                             RTX_LOAD_STATE(off, st);
                         }
                     } else if (at_prim(st)) {  // neither box (0) nor done / idle
@@ -1121,8 +1142,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                             const auto slots = slot_of(best.ent);
                             // uv costs an acos and an atan2: evaluate it only for materials whose texture reads it
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
-                            const float t_hit = SCALED ? best.t * PK_T_UNSCALE : best.t;  // exact: the factor is a power of two
-                            h = want_uv ? pk_make_hit<true, false, false>(S, slots, ray, t_hit) : pk_make_hit<false, false, false>(S, slots, ray, t_hit);
+                            h = want_uv ? pk_render_hit<SCALED, true, false>(S, slots, ray, best.t) : pk_render_hit<SCALED, false, false>(S, slots, ray, best.t);
                         } else {
                             uint4 ha, hb;
                             RTX_LOAD_ENTRY(best.ent, ha, hb);

@@ -298,17 +298,18 @@ __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, u
 }
 
 // One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
-template <bool STRICT, int SLAB>
+// QUICK: the primitive tests as the render kernels' fast walk evaluates them (hardware square root / reciprocal).
+template <bool STRICT, int SLAB, bool QUICK = false>
 __device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t off, const Ray& r, const RayConst& rc,
                                               float tmin, Best& best, const uint32_t* __restrict__ rank) {
     if (eb.w == ENT_BOX) return slab_hit<SLAB>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
     const uint32_t kind = eb.w & 15u;
     if (kind == ENT_SPHERE) {
-        sphere_test<STRICT>(ea, eb, r, rc, tmin, best, off, rank);
+        sphere_test<STRICT, 5, QUICK>(ea, eb, r, rc, tmin, best, off, rank);
     } else {
         const uint32_t pi = eb.w >> 4;
         const bool tri = kind == ENT_TRI;
-        planar_test<STRICT>(S.planar, tri ? pi + S.n_quads : pi, tri, r, tmin, best, off, rank);
+        planar_test<STRICT, QUICK>(S.planar, tri ? pi + S.n_quads : pi, tri, r, tmin, best, off, rank);
     }
     return off + ENT_BYTES;
 }
@@ -532,6 +533,29 @@ __device__ __forceinline__ HitRec pk_make_hit(const DevScene& S, LD ld, const Ra
     h.ny = front ? ny : -ny;
     h.nz = front ? nz : -nz;
     return h;
+}
+
+// The steps of the render kernels' walk over the packed array.  render_kernel and the trace kernel that gates its
+// arithmetic ray by ray (RTX_TRAVERSAL_RENDER) both call these, so what is checked is what is timed.
+// SCALED: float boxes (arrays sized for LDS), walk in scaled ray parameters; else half-precision boxes, plain parameters.
+template <bool SCALED>
+__device__ __forceinline__ bool pk_render_box(const uint4& e, const uint4& e1, const RayConst& rc, float tmin, float best_t) {
+    return SCALED ? pk_slab_hit_scaled(e, e1, rc, best_t) : pk_slab_hit(e, rc, tmin, best_t);
+}
+template <bool SCALED, class LD>
+__device__ __forceinline__ uint32_t pk_render_prim(const uint4& s0, const uint4& s1, LD ld, uint32_t off, const Ray& ray, const RayConst& rc, float tmin,
+                                                   Best& best, const uint32_t* __restrict__ rank) {
+    Best real = best;  // the primitive tests work in the ray's own parameter
+    if (SCALED) real.t = best.t * PK_T_UNSCALE;
+    const uint32_t size = pk_prim_test<true>(s0, s1, ld, off, ray, rc, tmin, real, rank);
+    best.ent = real.ent;
+    best.t = SCALED ? real.t * PK_T_SCALE : real.t;
+    return size;
+}
+template <bool SCALED, bool WANT_UV, bool IDS, class LD>
+__device__ __forceinline__ HitRec pk_render_hit(const DevScene& S, LD ld, const Ray& ray, float best_t) {
+    const float t_hit = SCALED ? best_t * PK_T_UNSCALE : best_t;  // exact: the factor is a power of two
+    return pk_make_hit<WANT_UV, false, IDS>(S, ld, ray, t_hit);
 }
 
 // ---------------------------------------------------------------------------------------------- brackets

@@ -21,7 +21,7 @@ from .scene import lower
 F = np.float32
 _DIR = os.path.dirname(os.path.abspath(__file__))
 
-TRAVERSAL_FAST, TRAVERSAL_STRICT, TRAVERSAL_FAST_FUSED = 0, 1, 2
+TRAVERSAL_FAST, TRAVERSAL_STRICT, TRAVERSAL_FAST_FUSED, TRAVERSAL_RENDER = 0, 1, 2, 3
 SPLIT_SAMPLES, SPLIT_TILES = 0, 1
 RTX_OK, RTX_ERR_INVALID, RTX_ERR_UNSUPPORTED, RTX_ERR_DEVICE, RTX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
