@@ -791,6 +791,168 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------- wide fast array
+// What the render kernels walk when a bracket-free scene is too large for LDS: the binary fast tree collapsed into nodes
+// of up to four children, each node one 128-byte line, and the primitives in a separate array of five-slot records.
+// A walk step then brings in two binary levels with one dependent fetch, and the primitives of every leaf a node hands
+// out are known at once.  Walking needs a per-lane stack (kept in LDS); its depth is bounded by `levels`.
+//   node, 8 slots of 16 bytes:
+//     (centre 0 .xyz, child_base)   (half extent 0 .xyz, prim_base)   (centre 1 .xyz, meta)   (half extent 1 .xyz, 0)
+//     (centre 2 .xyz, 0) (half extent 2 .xyz, 0) (centre 3 .xyz, 0) (half extent 3 .xyz, 0)
+//   Children that are nodes come first: child j < n_internal is node child_base + j (children of one node are
+//   contiguous).  A child that is a leaf owns count_j primitives; the primitives of a node's leaves follow each other
+//   from slot prim_base in child order.  meta = n_internal | count_0 << 3 | count_1 << 6 | count_2 << 9 | count_3 << 12.
+//   An unused child has half extent -inf (never hit).  Boxes are the fast tree's (padded) boxes in centre / half-extent
+//   form, the half extent rounded up.
+//   primitive, 5 slots: a sphere (c0.xyz, tag) (dc.xyz, r) + 3 unused slots; a quad / triangle as in the packed array.
+constexpr uint32_t WIDE_NODE_WORDS = 32;
+constexpr uint32_t WIDE_PRIM_SLOTS = 5;
+constexpr uint32_t WIDE_MAX_LEVELS = 32;  // deeper trees are not collapsed (the scene then keeps the packed array)
+constexpr uint32_t WIDE_MAX_LEAF = 7;     // primitives per leaf a node's meta word can count
+
+struct Wide {
+    std::vector<uint32_t> nodes;  // WIDE_NODE_WORDS per node, root first
+    std::vector<uint32_t> prims;  // 4 words per slot, WIDE_PRIM_SLOTS slots per primitive
+    std::vector<uint32_t> rank;   // per slot: tie-break rank of the primitive whose record starts there
+    std::vector<uint32_t> mat;    // per slot: its material, NONE elsewhere
+    uint32_t levels = 0;          // nodes on the longest path from the root
+    size_t n_nodes() const { return nodes.size() / WIDE_NODE_WORDS; }
+    size_t n_slots() const { return prims.size() / 4; }
+};
+
+class WideBuilder {
+  public:
+    WideBuilder(const Threaded& t_, const float* planar_, const uint32_t* planar_id_, uint32_t n_quads_, float grow_, Wide& out_)
+        : t(t_), planar(planar_), planar_id(planar_id_), n_quads(n_quads_), grow(grow_), out(out_) {}
+
+    bool run() {
+        if (t.has_brackets || t.ents.empty() || t.ents[0].w[7] != ENT_BOX) return false;
+        out = Wide();
+        out.nodes.assign(WIDE_NODE_WORDS, 0u);
+        if (!node(0, 0, 1)) return false;
+        return out.n_nodes() < (1u << 24) && out.n_slots() < (1u << 28);
+    }
+
+  private:
+    const Threaded& t;
+    const float* planar;
+    const uint32_t* planar_id;
+    uint32_t n_quads;
+    float grow;
+    Wide& out;
+
+    static float fval(uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    }
+    bool is_box(uint32_t e) const { return e < t.ents.size() && t.ents[e].w[7] == ENT_BOX; }
+    bool internal(uint32_t e) const { return is_box(e) && is_box(e + 1); }  // a box whose first child is a box has two box children
+    float area(uint32_t e) const {
+        const Ent& b = t.ents[e];
+        const float x = fval(b.w[1]) - fval(b.w[0]), y = fval(b.w[3]) - fval(b.w[2]), z = fval(b.w[5]) - fval(b.w[4]);
+        const float a = x * y + y * z + z * x;
+        return a == a ? a : std::numeric_limits<float>::infinity();
+    }
+    void put_box(uint32_t* c3, uint32_t* h3, uint32_t e) const {  // centre / half extent of box entry e, as pack() derives them
+        for (int a = 0; a < 3; a++) {
+            const float lo = fval(t.ents[e].w[2 * a]) - grow, hi = fval(t.ents[e].w[2 * a + 1]) + grow;
+            float c = 0.5f * lo + 0.5f * hi;
+            if (!std::isfinite(c)) c = 0.0f;
+            const double need = std::fmax((double)hi - (double)c, (double)c - (double)lo);
+            float h = (float)need;
+            if ((double)h < need) h = std::nextafter(h, std::numeric_limits<float>::infinity());
+            if (!(need == need)) h = std::numeric_limits<float>::infinity();  // NaN bounds: never cull
+            c3[a] = fbits(c);
+            h3[a] = fbits(h);
+        }
+    }
+    void put_prim(uint32_t p) {  // appends the five-slot record of primitive entry p
+        const Ent& e = t.ents[p];
+        const uint32_t kind = e.w[7] & 15u, index = e.w[7] >> 4;
+        const size_t at = out.prims.size();
+        out.prims.resize(at + 4 * WIDE_PRIM_SLOTS, 0u);
+        out.rank.resize(out.rank.size() + WIDE_PRIM_SLOTS, 0u);
+        out.mat.resize(out.mat.size() + WIDE_PRIM_SLOTS, NONE);
+        uint32_t* w = &out.prims[at];
+        out.rank[at / 4] = t.rank[p];
+        out.mat[at / 4] = t.mat[p];
+        if (kind == ENT_SPHERE) {
+            w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2]; w[3] = (ENT_SPHERE << 28) | index;
+            w[4] = e.w[3]; w[5] = e.w[4]; w[6] = e.w[5]; w[7] = e.w[6];
+        } else {
+            const size_t q = kind == ENT_TRI ? (size_t)index + n_quads : index;
+            const float* r = planar + 20 * q;  // (Q,d) (u,mat) (v,0) (n,0) (w,0)
+            std::memcpy(w + 0, r + 12, 12);  w[3] = (kind << 28) | index;   // n, tag
+            std::memcpy(w + 4, r + 0, 16);                                  // Q, d
+            std::memcpy(w + 8, r + 4, 16);                                  // u, material
+            std::memcpy(w + 12, r + 8, 12);  w[15] = planar_id[q];          // v, prim id
+            std::memcpy(w + 16, r + 16, 12); w[19] = 0;                     // w
+        }
+    }
+
+    // Fills node `ni` from the binary subtree under box entry `e`.
+    bool node(uint32_t ni, uint32_t e, uint32_t level) {
+        if (level > WIDE_MAX_LEVELS) return false;
+        out.levels = std::max(out.levels, level);
+        uint32_t kids[4];
+        uint32_t n = 0;
+        if (internal(e)) {
+            kids[n++] = e + 1;
+            kids[n++] = t.ents[e + 1].w[6];
+        } else {
+            kids[n++] = e;  // a tree that is one leaf
+        }
+        while (n < 4) {  // open the largest child that has children of its own
+            int pick = -1;
+            float best = -1.0f;
+            for (uint32_t k = 0; k < n; k++)
+                if (internal(kids[k]) && area(kids[k]) > best) {
+                    best = area(kids[k]);
+                    pick = (int)k;
+                }
+            if (pick < 0) break;
+            const uint32_t l = kids[pick] + 1, r = t.ents[l].w[6];
+            kids[pick] = l;
+            kids[n++] = r;
+        }
+        std::stable_partition(kids, kids + n, [&](uint32_t k) { return internal(k); });
+        uint32_t n_int = 0;
+        while (n_int < n && internal(kids[n_int])) n_int++;
+        const uint32_t child_base = (uint32_t)out.n_nodes();
+        out.nodes.resize(out.nodes.size() + (size_t)n_int * WIDE_NODE_WORDS, 0u);
+        const uint32_t prim_base = (uint32_t)out.n_slots();
+        uint32_t meta = n_int;
+        for (uint32_t k = n_int; k < n; k++) {
+            const uint32_t first = kids[k] + 1, end = t.ents[kids[k]].w[6], count = end - first;
+            if (count == 0 || count > WIDE_MAX_LEAF) return false;
+            for (uint32_t p = first; p < end; p++) {
+                if (t.ents[p].w[7] == ENT_BOX || (t.ents[p].w[7] & 15u) > ENT_TRI) return false;
+                put_prim(p);
+            }
+            meta |= count << (3 + 3 * k);
+        }
+        uint32_t* w = &out.nodes[(size_t)ni * WIDE_NODE_WORDS];
+        const float ninf = -std::numeric_limits<float>::infinity();
+        for (uint32_t k = 0; k < 4; k++) {
+            uint32_t* c = w + 8 * k;
+            uint32_t* h = w + 8 * k + 4;
+            if (k < n) {
+                put_box(c, h, kids[k]);
+            } else {
+                c[0] = c[1] = c[2] = 0u;
+                h[0] = h[1] = h[2] = fbits(ninf);
+            }
+        }
+        w[3] = child_base;
+        w[7] = prim_base;
+        w[11] = meta;
+        for (uint32_t k = 0; k < n_int; k++)
+            if (!node(child_base + k, kids[k], level + 1)) return false;
+        return true;
+    }
+};
+
 // Turn entry indices into byte offsets and append the terminator.
 static inline void finalize(Threaded& t) {
     const uint32_t S = (uint32_t)sizeof(Ent);

@@ -51,6 +51,12 @@ struct DevScene {
     const uint32_t* pk_rank;   // per slot: tie-break rank of the primitive whose entry starts there
     const uint4* pk_shade;     // per slot, 2 x uint4 in the layout of `shade`; null when the array is too large for LDS
     const uint4* mat_recs;     // 2 x uint4 per material: the record `shade` holds for an entry of that material
+    // The wide form of the fast array (four-child nodes of 128 bytes + five-slot primitive records; see accel.hpp), null
+    // unless the scene is bracket-free and too large for LDS.  The render kernels then walk it instead of `pk`.
+    const uint4* wnodes;       // 8 x uint4 per node, root first
+    const uint4* wprims;       // 5 x uint4 per primitive
+    const uint32_t* wrank;     // per slot of wprims: tie-break rank of the primitive whose record starts there
+    uint32_t w_levels;         // nodes on the longest path from the root = groups a walk can have pending + 1
 };
 
 struct Ray {
@@ -223,12 +229,40 @@ __device__ __forceinline__ bool in_range(float t, float tmin, const Best& b, uin
     return t == b.t && b.ent != NO_HIT && rank[off >> SHIFT] < rank[b.ent >> SHIFT];
 }
 
+// Square root and quotient for the render kernels' fast walk: the hardware's reciprocal square root / reciprocal (one
+// unit in the last place) followed by one Newton step on the residual, which a fused multiply-add yields exactly.  The
+// result is the correctly rounded one -- the reference's -- for all but a vanishing share of operands, at 5 + 2 plain
+// multiply-adds instead of the ~12 + ~10 instructions of the guaranteed sequences.  A sphere's root is a difference of
+// two numbers much larger than itself when the origin is near the surface of a large sphere; with the square root equal
+// bit for bit that difference is too, and the hit distance agrees with the reference's to the last place or two.
+//   quick_sqrt: x >= 0; x below 1e-37 (but for 0, which gives 0) is not supported.
+//   quick_div : r = rcp(d) is passed in so that two quotients by one divisor share it.
+__device__ __forceinline__ float quick_sqrt(float x) {
+#ifdef RTX_QUICK_PLAIN
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 1e-37f));  // (finite for x = 0, so that s = e = 0 below)
+    const float s = x * y;
+    const float e = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(e, 0.5f * y, s);
+#endif
+}
+__device__ __forceinline__ float quick_div(float n, float d, float r) {
+#ifdef RTX_QUICK_PLAIN
+    return n * r;
+#else
+    const float q = n * r;
+    const float e = __builtin_fmaf(-q, d, n);
+    return __builtin_fmaf(e, r, q);
+#endif
+}
+
 // Sphere::hit up to the accepted root (mesh.rs:113-133).
-//  QUICK : the two roots through the hardware square root and reciprocal (about 1 ulp each) instead of the correctly
-//          rounded sqrt and two divisions, which expand to ~35 instructions.  t then differs from the reference's by a
-//          few ulps -- far inside the 1e-5 tolerance on hit distances -- so only the render kernels' fast walk uses it;
-//          rtx_trace, the parity gate for ids and t, always computes the roots exactly.  Equal inputs still give equal
-//          roots, so coincident primitives tie as before.
+//  QUICK : the two roots through quick_sqrt / quick_div (hardware reciprocal square root and reciprocal, one Newton step
+//          each) instead of the guaranteed correctly rounded sqrt and two divisions, which expand to ~35 instructions.
+//          Only the render kernels' fast walk uses it (and the trace mode that gates it, RTX_TRAVERSAL_RENDER: hit
+//          distances bit-equal to the oracle's on every ray measured); the other trace modes compute the roots with the
+//          guaranteed sequences.  Equal inputs give equal roots, so coincident primitives tie as before.
 template <bool STRICT, int SHIFT = 5, bool QUICK = false>
 __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, const Ray& r, const RayConst& rc, float tmin, Best& best,
                                             uint32_t idx, const uint32_t* __restrict__ rank) {
@@ -244,10 +278,10 @@ __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, co
     if (disc < 0.0f) return;
     float root;
     if (QUICK) {
-        const float sqrtd = __builtin_amdgcn_sqrtf(disc);
+        const float sqrtd = quick_sqrt(disc);
         const float inv_a = __builtin_amdgcn_rcpf(rc.a);
-        root = (h - sqrtd) * inv_a;
-        if (!(tmin <= root)) root = (h + sqrtd) * inv_a;
+        root = quick_div(h - sqrtd, rc.a, inv_a);
+        if (!(tmin <= root)) root = quick_div(h + sqrtd, rc.a, inv_a);
         if (!in_range<false, SHIFT>(root, tmin, best, idx, rank)) return;
     } else {
         const float sqrtd = __builtin_sqrtf(disc);
@@ -269,7 +303,7 @@ __device__ __forceinline__ void sphere_test(const uint4& ea, const uint4& eb, co
 
 // Quad::hit (mesh.rs:202-221, :248-256); TRI uses the same plane / alpha / beta with the triangle's domain.
 // LD(k) returns record k of the primitive: 0 (Q.xyz, d)  1 (u.xyz, ..)  2 (v.xyz, ..)  3 (n.xyz, ..)  4 (w.xyz, ..).
-// QUICK (render kernels' fast walk only): the division through the hardware reciprocal.
+// QUICK (render kernels' fast walk only): the division through quick_div.
 template <bool STRICT, int SHIFT, bool QUICK = false, class LD>
 __device__ __forceinline__ void planar_test_ld(LD ld, bool is_tri, const Ray& r, float tmin, Best& best, uint32_t idx,
                                                const uint32_t* __restrict__ rank) {
@@ -278,7 +312,7 @@ __device__ __forceinline__ void planar_test_ld(LD ld, bool is_tri, const Ray& r,
     float denom = dot3(n.x, n.y, n.z, r.dx, r.dy, r.dz);
     if (fabsf(denom) < 1e-8f) return;
     const float num = q.w - dot3(n.x, n.y, n.z, r.ox, r.oy, r.oz);
-    float t = QUICK ? num * __builtin_amdgcn_rcpf(denom) : num / denom;
+    float t = QUICK ? quick_div(num, denom, __builtin_amdgcn_rcpf(denom)) : num / denom;
     if (!in_range<STRICT, SHIFT>(t, tmin, best, idx, rank)) return;
     const float4 u = ld(1), v = ld(2), w = ld(4);
     float px = (r.ox + r.dx * t) - q.x, py = (r.oy + r.dy * t) - q.y, pz = (r.oz + r.dz * t) - q.z;
@@ -332,8 +366,8 @@ __device__ __forceinline__ void sphere_uv(float nx, float ny, float nz, float& u
 }
 
 // The rest of Sphere::hit / Quad::hit after the root is accepted, plus Hit::new (mesh.rs:33-51, :135-138, :214-220).
-// EXACT = true divides by the radius as the reference does (bit-identical normals, rtx_trace); false multiplies by the
-// hardware reciprocal (normals within ~2 ulp, far inside the 1e-5 tolerance; used where only shading consumes them).
+// EXACT = true divides by the radius as the reference does (bit-identical normals, rtx_trace); false takes the quotient
+// through the hardware reciprocal and one Newton step (quick_div: the same bits for all but a vanishing share of operands).
 template <bool WANT_UV, bool EXACT = true>
 __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, const uint4& eb, const Ray& r, float t) {
     HitRec h;
@@ -353,9 +387,9 @@ __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, c
             nz = (h.pz - cz) / radius;
         } else {
             const float inv_r = __builtin_amdgcn_rcpf(radius);
-            nx = (h.px - cx) * inv_r;
-            ny = (h.py - cy) * inv_r;
-            nz = (h.pz - cz) * inv_r;
+            nx = quick_div(h.px - cx, radius, inv_r);
+            ny = quick_div(h.py - cy, radius, inv_r);
+            nz = quick_div(h.pz - cz, radius, inv_r);
         }
         h.u = 0.0f;
         h.v = 0.0f;
@@ -502,9 +536,9 @@ __device__ __forceinline__ HitRec pk_make_hit(const DevScene& S, LD ld, const Ra
             nz = (h.pz - cz) / radius;
         } else {
             const float inv_r = __builtin_amdgcn_rcpf(radius);
-            nx = (h.px - cx) * inv_r;
-            ny = (h.py - cy) * inv_r;
-            nz = (h.pz - cz) * inv_r;
+            nx = quick_div(h.px - cx, radius, inv_r);
+            ny = quick_div(h.py - cy, radius, inv_r);
+            nz = quick_div(h.pz - cz, radius, inv_r);
         }
         if (WANT_UV) sphere_uv(nx, ny, nz, h.u, h.v);
         if (IDS) {
@@ -556,6 +590,80 @@ template <bool SCALED, bool WANT_UV, bool IDS, class LD>
 __device__ __forceinline__ HitRec pk_render_hit(const DevScene& S, LD ld, const Ray& ray, float best_t) {
     const float t_hit = SCALED ? best_t * PK_T_UNSCALE : best_t;  // exact: the factor is a power of two
     return pk_make_hit<WANT_UV, false, IDS>(S, ld, ray, t_hit);
+}
+
+// ---------------------------------------------------------------------------------------------- wide fast array
+// One walk step at a four-child node (layout: accel.hpp).  Tests the four child boxes in centre / half-extent form (as
+// pk_slab_hit does for one box) against [tmin, tmax], and reports
+//   next   the nearest child node that was hit (WIDE_NONE if none),
+//   group  the other child nodes that were hit, nearest first, as one word:
+//            node index of child 0 << 8 | up to three 2-bit child numbers from bit 2 | how many (bits 0-1); 0 if none
+//   tbase, tmask   the primitives of the leaves that were hit: bit i = the i-th primitive record from slot tbase.
+// Children are sorted by the distance at which the ray enters their boxes (ties and the order among leaves do not matter:
+// the closest hit does not depend on the visiting order).  The child number rides in the two low bits of the distance's
+// bit pattern, so sorting four words sorts the children; distances are >= tmin >= 0 in the render kernels, where bit
+// patterns order like the values (a negative tmin in rtx_trace only costs ordering quality, never a hit).
+constexpr uint32_t WIDE_NONE = 0xFFFFFFFFu;
+constexpr uint32_t WIDE_NODE_BYTES = 128u;
+constexpr uint32_t WIDE_PRIM_BYTES = 80u;
+
+__device__ __forceinline__ uint32_t wide_child_key(const uint4& c, const uint4& h, const RayConst& rc, float ax, float ay, float az, float tmin,
+                                                   float tmax, uint32_t j) {
+    const float tcx = __builtin_fmaf(as_f(c.x), rc.ix, rc.nx);
+    const float tcy = __builtin_fmaf(as_f(c.y), rc.iy, rc.ny);
+    const float tcz = __builtin_fmaf(as_f(c.z), rc.iz, rc.nz);
+    const float hx = as_f(h.x), hy = as_f(h.y), hz = as_f(h.z);
+    const float enter = fmaxf(fmaxf(__builtin_fmaf(-hx, ax, tcx), __builtin_fmaf(-hy, ay, tcy)), fmaxf(__builtin_fmaf(-hz, az, tcz), tmin));
+    const float exit3 = fminf(fminf(__builtin_fmaf(hx, ax, tcx), __builtin_fmaf(hy, ay, tcy)), __builtin_fmaf(hz, az, tcz));
+    float exit;
+    asm("v_min_f32 %0, %1, %2" : "=v"(exit) : "v"(exit3), "v"(tmax));  // (no re-quieting of the interval end, as in slab_hit)
+    return (exit <= enter) ? 0xFFFFFFFFu : ((__float_as_uint(enter) & ~3u) | j);
+}
+
+template <class LD>
+__device__ __forceinline__ void wide_node_step(LD ld, const RayConst& rc, float tmin, float tmax, uint32_t& next, uint32_t& group, uint32_t& tbase,
+                                               uint32_t& tmask, uint32_t& n_children) {
+    const uint4 c0 = ld(0), h0 = ld(1), c1 = ld(2), h1 = ld(3), c2 = ld(4), h2 = ld(5), c3 = ld(6), h3 = ld(7);
+    const uint32_t child_base = c0.w, meta = c1.w;
+    const uint32_t n_int = meta & 7u;
+    const float ax = __builtin_fabsf(rc.ix), ay = __builtin_fabsf(rc.iy), az = __builtin_fabsf(rc.iz);
+    uint32_t k0 = wide_child_key(c0, h0, rc, ax, ay, az, tmin, tmax, 0u);
+    uint32_t k1 = wide_child_key(c1, h1, rc, ax, ay, az, tmin, tmax, 1u);
+    uint32_t k2 = wide_child_key(c2, h2, rc, ax, ay, az, tmin, tmax, 2u);
+    uint32_t k3 = wide_child_key(c3, h3, rc, ax, ay, az, tmin, tmax, 3u);
+    // leaves that were hit hand out their primitives
+    const uint32_t n0 = (meta >> 3) & 7u, n1 = (meta >> 6) & 7u, n2 = (meta >> 9) & 7u, n3 = (meta >> 12) & 7u;
+    uint32_t mask = 0u;
+    if (k0 != 0xFFFFFFFFu) mask |= (1u << n0) - 1u;
+    if (k1 != 0xFFFFFFFFu) mask |= ((1u << n1) - 1u) << n0;
+    if (k2 != 0xFFFFFFFFu) mask |= ((1u << n2) - 1u) << (n0 + n1);
+    if (k3 != 0xFFFFFFFFu) mask |= ((1u << n3) - 1u) << (n0 + n1 + n2);
+    tbase = h0.w;
+    tmask = mask;
+    n_children = n_int + (n0 != 0u) + (n1 != 0u) + (n2 != 0u) + (n3 != 0u);
+    // child nodes (children 0 .. n_int - 1) that were hit, nearest first
+    if (0u >= n_int) k0 = 0xFFFFFFFFu;
+    if (1u >= n_int) k1 = 0xFFFFFFFFu;
+    if (2u >= n_int) k2 = 0xFFFFFFFFu;
+    if (3u >= n_int) k3 = 0xFFFFFFFFu;
+    uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
+    k0 = min(a, c);
+    const uint32_t m1 = max(a, c), m2 = min(b, d);
+    k3 = max(b, d);
+    k1 = min(m1, m2);
+    k2 = max(m1, m2);
+    const uint32_t hits = (k0 != 0xFFFFFFFFu) + (k1 != 0xFFFFFFFFu) + (k2 != 0xFFFFFFFFu) + (k3 != 0xFFFFFFFFu);
+    next = hits != 0u ? child_base + (k0 & 3u) : WIDE_NONE;
+    group = hits > 1u ? (child_base << 8) | ((k1 & 3u) << 2) | ((k2 & 3u) << 4) | ((k3 & 3u) << 6) | (hits - 1u) : 0u;
+}
+
+// Takes the next child node out of a pending group: returns its node index and leaves the group with one child fewer
+// (0 when it was the last).  The group must not be 0.
+__device__ __forceinline__ uint32_t wide_group_pop(uint32_t& group) {
+    const uint32_t node = (group >> 8) + ((group >> 2) & 3u);
+    const uint32_t left = (group & 3u) - 1u;
+    group = left != 0u ? ((group & 0xFFFFFF00u) | ((group >> 2) & 0x3Cu) | left) : 0u;
+    return node;
 }
 
 // ---------------------------------------------------------------------------------------------- brackets

@@ -309,19 +309,18 @@ def test_viewpoint_ordering_keeps_every_hit(render, oracle, scenes, name, seed):
 
 @pytest.mark.parametrize("name,seed", [("bouncing-spheres", 1), ("quads", 0), ("earth", 0), ("simple-light", 1), ("cornell-box", 0)])
 def test_strict_and_fast_render_agree(render, scenes, name, seed):
-    """Same seed, both traversal modes.  The fast walk tests other boxes but finds the same hits; in the render kernels it
-    also takes a sphere's roots and a quad's plane distance through the hardware square root and reciprocal, so a hit
-    distance can differ from the strict walk's by a few ulps.  Paths are chaotic (a bounce off a small sphere magnifies a deviation), so a small
-    share of the samples ends elsewhere: most pixel values are identical, nearly all agree to 1e-4, and the frames'
-    means agree.  quads, earth and simple-light look at the scene from outside its own coordinate range: the fast
-    boxes are enlarged for that distance instead of falling back to the strict walk."""
+    """Same seed, both traversal modes.  The fast walk tests other boxes but finds the same hits, with the same bits
+    (tests/test_gpu_render_walk.py); a frame differs only where the reference's own box test culls a hit by rounding
+    (mesh.rs:532 is not conservative) and in the order of fp32 additions.  quads, earth and simple-light look at the scene
+    from outside its own coordinate range: the fast boxes are enlarged for that distance instead of falling back to the
+    strict walk."""
     cfg, bvh = scenes.make(name, seed=seed, width=160, height=90, samples_per_pixel=8)
     scene, cam = render.Scene(bvh), render.Camera(cfg)
     _, a = cam.render(scene, seed=3, traversal=render.TRAVERSAL_FAST, want_accum=True)
     _, b = cam.render(scene, seed=3, traversal=render.TRAVERSAL_STRICT, want_accum=True)
     rel = np.abs(a - b) / (np.abs(b) + 1e-2)
     assert np.median(rel) < 1e-6
-    assert np.mean(rel < 1e-4) > 0.97, float(np.mean(rel < 1e-4))
+    assert np.mean(rel < 1e-4) > 0.999, float(np.mean(rel < 1e-4))
     assert abs(a.mean() - b.mean()) < 5e-3 * abs(b.mean())
 
 
