@@ -247,7 +247,8 @@ typedef struct rtx_stats {
     double kernel_ms;     /* device time of the path-tracing kernel(s), HIP events on the launch stream */
     double total_ms;      /* wall time of the call */
     uint32_t n_launches;  /* launches of the dominant kernel */
-    uint32_t flags;       /* bit 0: the traversal entries were resident in LDS (small scene); else walked from HBM / L2.
+    uint32_t flags;       /* bit 2: the wide form was walked (four-child nodes of 64 B, primitives of 80 B; see rtx_wide_dump).
+                           * bit 0: the traversal entries were resident in LDS (small scene); else walked from HBM / L2.
                            * bit 1: the packed array was walked (16-byte slots: a box is 16 B in HBM, 32 B in LDS; a sphere 32 B;
                            * a quad / triangle 80 B) instead of 32-byte entries with separate 80-byte planar records */
     uint64_t box_tests;   /* Aabb::hit evaluations the kernel performed (lanes x box steps), counted in the kernel */
@@ -335,6 +336,20 @@ int rtx_resolve(const float* accum_dev, uint32_t width, uint32_t height, float s
  * slots, rank_out gets one word per slot (RTX_ERR_UNSUPPORTED for a scene with transforms or media). */
 int rtx_traversal_dump(const rtx_scene_desc_t* desc, uint32_t traversal, const float* view, float grow,
                        uint32_t* entries_out, uint32_t* rank_out, size_t capacity, size_t* n_entries);
+
+/* Inspection, host only, like rtx_traversal_dump: the WIDE form of the fast traversal data, which the render kernels walk
+ * for scenes without Translate / RotateY / ConstantMedium that are too large for on-chip memory (no counterpart in the
+ * reference; replaces Bvh::hit's recursion, mesh.rs:607-625, like the other forms).  nodes_out: 16 words per node --
+ * four 16-byte slots (origin.xyz, child_base) (scale.xyz, prim_base) (lo_x, lo_y, lo_z, leaves) (hi_x, hi_y, hi_z,
+ * n_internal): a node has up to four children; byte j of lo_a / hi_a bounds child j on axis a as
+ * [origin_a + scale_a * lo, origin_a + scale_a * hi] (an unused child: lo 255, hi 0).  Children j < n_internal are the
+ * nodes child_base + j; the others are leaves whose primitives lie one after the other from slot prim_base in child
+ * order: byte j of `leaves` = count << 5 | index of the leaf's first primitive record among the node's.
+ * prims_out: 4 words per slot, 5 slots per primitive, laid out as the packed form's entries (a sphere uses two of its
+ * five).  rank_out: one word per slot.  levels: nodes on the longest path from the root.  With both output pointers
+ * NULL only the counts are set.  RTX_ERR_UNSUPPORTED when the scene has no wide form. */
+int rtx_wide_dump(const rtx_scene_desc_t* desc, float grow, uint32_t* nodes_out, size_t node_capacity, uint32_t* prims_out,
+                  uint32_t* rank_out, size_t slot_capacity, size_t* n_nodes, size_t* n_slots, uint32_t* levels);
 
 #ifdef __cplusplus
 }

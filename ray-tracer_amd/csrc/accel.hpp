@@ -793,22 +793,26 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
 
 // ---------------------------------------------------------------------------------------------- wide fast array
 // What the render kernels walk when a bracket-free scene is too large for LDS: the binary fast tree collapsed into nodes
-// of up to four children, each node one 128-byte line, and the primitives in a separate array of five-slot records.
-// A walk step then brings in two binary levels with one dependent fetch, and the primitives of every leaf a node hands
-// out are known at once.  Walking needs a per-lane stack (kept in LDS); its depth is bounded by `levels`.
-//   node, 8 slots of 16 bytes:
-//     (centre 0 .xyz, child_base)   (half extent 0 .xyz, prim_base)   (centre 1 .xyz, meta)   (half extent 1 .xyz, 0)
-//     (centre 2 .xyz, 0) (half extent 2 .xyz, 0) (centre 3 .xyz, 0) (half extent 3 .xyz, 0)
+// of up to four children, each node 64 bytes (half a cache line), and the primitives in a separate array of five-slot
+// records.  Such a walk is bound by the bytes its lanes pull through the vector memory path, one dependent fetch after
+// the other: a node brings in two binary levels with one 64-byte fetch (the binary form: 16 bytes per box, but one fetch
+// per box), and the primitives of every leaf a node hands out are known at once.  Walking needs a per-lane stack (kept
+// in LDS); its depth is bounded by `levels`.
+//   node, 4 slots of 16 bytes:
+//     (origin.xyz, child_base)   (scale.xyz, prim_base)   (lo_x, lo_y, lo_z, leaves)   (hi_x, hi_y, hi_z, n_internal)
+//   origin = the low corner of the box around all children, scale = its extent / 255 (rounded up).  lo_a / hi_a hold one
+//   byte per child (child j in bits 8j .. 8j+7): the child's box on axis a is [origin_a + scale_a * lo, origin_a +
+//   scale_a * hi], rounded outward from the fast tree's (padded) box, so a quantised box always contains the box it
+//   stands for.  An unused child has lo = 255, hi = 0 on every axis (never hit).
 //   Children that are nodes come first: child j < n_internal is node child_base + j (children of one node are
-//   contiguous).  A child that is a leaf owns count_j primitives; the primitives of a node's leaves follow each other
-//   from slot prim_base in child order.  meta = n_internal | count_0 << 3 | count_1 << 6 | count_2 << 9 | count_3 << 12.
-//   An unused child has half extent -inf (never hit).  Boxes are the fast tree's (padded) boxes in centre / half-extent
-//   form, the half extent rounded up.
+//   contiguous).  A child that is a leaf owns some of the node's primitives, which follow each other from slot prim_base
+//   in child order: byte j of `leaves` = count << 5 | index of its first primitive record among the node's (0 for a child
+//   node and for an unused child).
 //   primitive, 5 slots: a sphere (c0.xyz, tag) (dc.xyz, r) + 3 unused slots; a quad / triangle as in the packed array.
-constexpr uint32_t WIDE_NODE_WORDS = 32;
+constexpr uint32_t WIDE_NODE_WORDS = 16;
 constexpr uint32_t WIDE_PRIM_SLOTS = 5;
 constexpr uint32_t WIDE_MAX_LEVELS = 32;  // deeper trees are not collapsed (the scene then keeps the packed array)
-constexpr uint32_t WIDE_MAX_LEAF = 7;     // primitives per leaf a node's meta word can count
+constexpr uint32_t WIDE_MAX_LEAF = 7;     // primitives per leaf: three bits count them, five bits say where they start
 
 struct Wide {
     std::vector<uint32_t> nodes;  // WIDE_NODE_WORDS per node, root first
@@ -830,7 +834,7 @@ class WideBuilder {
         out = Wide();
         out.nodes.assign(WIDE_NODE_WORDS, 0u);
         if (!node(0, 0, 1)) return false;
-        return out.n_nodes() < (1u << 24) && out.n_slots() < (1u << 28);
+        return out.n_nodes() < (1u << 23) && out.n_slots() < (1u << 28);
     }
 
   private:
@@ -854,18 +858,18 @@ class WideBuilder {
         const float a = x * y + y * z + z * x;
         return a == a ? a : std::numeric_limits<float>::infinity();
     }
-    void put_box(uint32_t* c3, uint32_t* h3, uint32_t e) const {  // centre / half extent of box entry e, as pack() derives them
+    bool box_of(uint32_t e, double lo[3], double hi[3]) const {  // box entry e, enlarged by `grow`; false when it is not finite
         for (int a = 0; a < 3; a++) {
-            const float lo = fval(t.ents[e].w[2 * a]) - grow, hi = fval(t.ents[e].w[2 * a + 1]) + grow;
-            float c = 0.5f * lo + 0.5f * hi;
-            if (!std::isfinite(c)) c = 0.0f;
-            const double need = std::fmax((double)hi - (double)c, (double)c - (double)lo);
-            float h = (float)need;
-            if ((double)h < need) h = std::nextafter(h, std::numeric_limits<float>::infinity());
-            if (!(need == need)) h = std::numeric_limits<float>::infinity();  // NaN bounds: never cull
-            c3[a] = fbits(c);
-            h3[a] = fbits(h);
+            lo[a] = (double)(fval(t.ents[e].w[2 * a]) - grow);
+            hi[a] = (double)(fval(t.ents[e].w[2 * a + 1]) + grow);
+            if (!std::isfinite(lo[a]) || !std::isfinite(hi[a]) || std::fabs(lo[a]) > 1e30 || std::fabs(hi[a]) > 1e30) return false;
         }
+        return true;
+    }
+    float extent(uint32_t e) const {  // largest side of box entry e
+        const Ent& b = t.ents[e];
+        const float m = std::fmax(fval(b.w[1]) - fval(b.w[0]), std::fmax(fval(b.w[3]) - fval(b.w[2]), fval(b.w[5]) - fval(b.w[4])));
+        return m == m ? m : std::numeric_limits<float>::infinity();
     }
     void put_prim(uint32_t p) {  // appends the five-slot record of primitive entry p
         const Ent& e = t.ents[p];
@@ -903,11 +907,15 @@ class WideBuilder {
         } else {
             kids[n++] = e;  // a tree that is one leaf
         }
-        while (n < 4) {  // open the largest child that has children of its own
+        // Open the largest child that has children of its own -- unless it is small against the node: its children's boxes
+        // go onto the node's 256-step grid, where anything much smaller than a grid step is as good as lost (a mesh of
+        // size 1 beside a ground sphere of radius 1000: the mesh stays one child here and gets a grid of its own below).
+        const float open_min = extent(e) * (1.0f / 16.0f);
+        while (n < 4) {
             int pick = -1;
             float best = -1.0f;
             for (uint32_t k = 0; k < n; k++)
-                if (internal(kids[k]) && area(kids[k]) > best) {
+                if (internal(kids[k]) && extent(kids[k]) >= open_min && area(kids[k]) > best) {
                     best = area(kids[k]);
                     pick = (int)k;
                 }
@@ -922,7 +930,7 @@ class WideBuilder {
         const uint32_t child_base = (uint32_t)out.n_nodes();
         out.nodes.resize(out.nodes.size() + (size_t)n_int * WIDE_NODE_WORDS, 0u);
         const uint32_t prim_base = (uint32_t)out.n_slots();
-        uint32_t meta = n_int;
+        uint32_t leaves = 0u, n_prims = 0;
         for (uint32_t k = n_int; k < n; k++) {
             const uint32_t first = kids[k] + 1, end = t.ents[kids[k]].w[6], count = end - first;
             if (count == 0 || count > WIDE_MAX_LEAF) return false;
@@ -930,23 +938,51 @@ class WideBuilder {
                 if (t.ents[p].w[7] == ENT_BOX || (t.ents[p].w[7] & 15u) > ENT_TRI) return false;
                 put_prim(p);
             }
-            meta |= count << (3 + 3 * k);
+            leaves |= ((count << 5) | n_prims) << (8 * k);
+            n_prims += count;
         }
+        // the box around all children and the children's boxes on its 256-step grid, rounded outward
+        double lo[4][3], hi[4][3], nlo[3], nhi[3];
+        for (uint32_t k = 0; k < n; k++)
+            if (!box_of(kids[k], lo[k], hi[k])) return false;
         uint32_t* w = &out.nodes[(size_t)ni * WIDE_NODE_WORDS];
-        const float ninf = -std::numeric_limits<float>::infinity();
-        for (uint32_t k = 0; k < 4; k++) {
-            uint32_t* c = w + 8 * k;
-            uint32_t* h = w + 8 * k + 4;
-            if (k < n) {
-                put_box(c, h, kids[k]);
-            } else {
-                c[0] = c[1] = c[2] = 0u;
-                h[0] = h[1] = h[2] = fbits(ninf);
+        uint32_t qlo[3] = {0u, 0u, 0u}, qhi[3] = {0u, 0u, 0u};
+        for (int a = 0; a < 3; a++) {
+            nlo[a] = lo[0][a];
+            nhi[a] = hi[0][a];
+            for (uint32_t k = 1; k < n; k++) {
+                nlo[a] = std::fmin(nlo[a], lo[k][a]);
+                nhi[a] = std::fmax(nhi[a], hi[k][a]);
             }
+            float origin = (float)nlo[a];
+            if ((double)origin > nlo[a]) origin = std::nextafter(origin, -std::numeric_limits<float>::infinity());
+            float scale = (float)((nhi[a] - (double)origin) / 255.0);
+            scale = std::nextafter(std::fmax(scale, 1e-30f), std::numeric_limits<float>::infinity());
+            while ((double)origin + 255.0 * (double)scale < nhi[a]) scale = std::nextafter(scale, std::numeric_limits<float>::infinity());
+            w[a] = fbits(origin);
+            w[4 + a] = fbits(scale);
+            for (uint32_t k = 0; k < 4; k++) {
+                uint32_t l = 255u, h = 0u;  // an unused child is never hit
+                if (k < n) {
+                    double fl = std::floor((lo[k][a] - (double)origin) / (double)scale), fh = std::ceil((hi[k][a] - (double)origin) / (double)scale);
+                    fl = std::fmin(std::fmax(fl, 0.0), 255.0);
+                    fh = std::fmin(std::fmax(fh, 0.0), 255.0);
+                    while (fl > 0.0 && (double)origin + fl * (double)scale > lo[k][a]) fl -= 1.0;
+                    while (fh < 255.0 && (double)origin + fh * (double)scale < hi[k][a]) fh += 1.0;
+                    if ((double)origin + fl * (double)scale > lo[k][a] || (double)origin + fh * (double)scale < hi[k][a]) return false;
+                    l = (uint32_t)fl;
+                    h = (uint32_t)fh;
+                }
+                qlo[a] |= l << (8 * k);
+                qhi[a] |= h << (8 * k);
+            }
+            w[8 + a] = qlo[a];
+            w[12 + a] = qhi[a];
         }
         w[3] = child_base;
         w[7] = prim_base;
-        w[11] = meta;
+        w[11] = leaves;
+        w[15] = n_int;
         for (uint32_t k = 0; k < n_int; k++)
             if (!node(child_base + k, kids[k], level + 1)) return false;
         return true;

@@ -48,7 +48,7 @@ constexpr uint32_t MAX_ITEM_SLOTS_HOST = 8;  // items in flight per wave, upper 
 // Tuning knobs, read from the environment once per process.
 struct Knobs {
     uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, planar_lds_max, perlin_lds, waves_per_block,
-        blocks_per_cu, debug;
+        blocks_per_cu, debug, wide, w_mix, sched_k_wide;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -71,6 +71,9 @@ static const Knobs& knobs() {
         x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
         x.blocks_per_cu = u("RTX_BLOCKS_PER_CU", 0);
         x.debug = u("RTX_DEBUG", 0);
+        x.wide = u("RTX_WIDE", 1);
+        x.w_mix = u("RTX_W_MIX", 3);
+        x.sched_k_wide = std::max(1u, u("RTX_SCHED_K_WIDE", 3));
         return x;
     }();
     return k;
@@ -100,6 +103,7 @@ struct DeviceCopy {
     float view[3] = {0, 0, 0};
     float view_grow = 0.0f;
     bool view_valid = false;
+    float wide_grow = 0.0f;  // how far the boxes of this copy's wide nodes are enlarged
     // rtx_render_multi only: this share's stream, sums and bytes; staging slots on the gathering device
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
@@ -128,6 +132,9 @@ struct rtx_scene {
     uint32_t pk_slots = 0;
     uint32_t n_quads = 0;
     uint32_t n_planar = 0;  // quads + triangles (80-byte records)
+    // wide form of the fast array (bracket-free scenes too large for LDS): what the render kernels walk instead of the packed one
+    bool wide = false;
+    uint32_t w_nodes = 0, w_slots = 0, w_levels = 0;
     std::vector<float4> planar_host;      // 5 per quad / triangle, as uploaded
     std::vector<uint32_t> planar_id_host;
 };
@@ -330,6 +337,33 @@ extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal,
     return RTX_OK;
 }
 
+extern "C" int rtx_wide_dump(const rtx_scene_desc_t* d, float grow, uint32_t* nodes_out, size_t node_capacity, uint32_t* prims_out, uint32_t* rank_out,
+                             size_t slot_capacity, size_t* n_nodes, size_t* n_slots, uint32_t* levels) {
+    if (!n_nodes || !n_slots) return fail(RTX_ERR_INVALID, "null argument");
+    int rc = validate(d);
+    if (rc != RTX_OK) return rc;
+    rtx_accel::Threaded strict, fast, indexed;
+    std::string err;
+    float range = 0.0f;
+    rc = rtx_accel::build(*d, strict, fast, indexed, range, err);
+    if (rc != RTX_OK) return fail(rc, err);
+    std::vector<float4> planar;
+    std::vector<uint32_t> planar_id;
+    build_planar(*d, planar, planar_id);
+    rtx_accel::Wide w;
+    if (!rtx_accel::WideBuilder(indexed, reinterpret_cast<const float*>(planar.data()), planar_id.data(), d->n_quads, grow, w).run())
+        return fail(RTX_ERR_UNSUPPORTED, "no wide array for this scene (Translate / RotateY / ConstantMedium, or a tree deeper than the walk's stack)");
+    *n_nodes = w.n_nodes();
+    *n_slots = w.n_slots();
+    if (levels) *levels = w.levels;
+    if (!nodes_out && !prims_out) return RTX_OK;
+    if (node_capacity < w.n_nodes() || slot_capacity < w.n_slots()) return fail(RTX_ERR_INVALID, "capacity too small");
+    if (nodes_out) std::memcpy(nodes_out, w.nodes.data(), w.nodes.size() * 4);
+    if (prims_out) std::memcpy(prims_out, w.prims.data(), w.prims.size() * 4);
+    if (rank_out) std::memcpy(rank_out, w.rank.data(), w.rank.size() * 4);
+    return RTX_OK;
+}
+
 // Per-entry shading records of a threaded array: the record of the entry's material, zeros where nothing can be hit.
 static std::vector<uint4> expand_shade(const rtx_accel::Threaded& t, const std::vector<uint4>& mat_recs) {
     std::vector<uint4> out(2 * t.ents.size(), make_uint4(0, 0, 0, 0));
@@ -447,6 +481,21 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
             }
             s->planar_host = planar;
             s->planar_id_host = planar_id;
+        }
+        if (s->packed && s->pk_half && knobs().wide != 0u) {
+            rtx_accel::Wide w;
+            if (rtx_accel::WideBuilder(s->fast_indexed, reinterpret_cast<const float*>(planar.data()), planar_id.data(), d->n_quads, 0.0f, w).run()) {
+                std::vector<uint4> n4(w.nodes.size() / 4), p4(w.prims.size() / 4);
+                std::memcpy(n4.data(), w.nodes.data(), w.nodes.size() * 4);
+                std::memcpy(p4.data(), w.prims.data(), w.prims.size() * 4);
+                if ((rc = upload(dc, n4, &dc->dev.wnodes)) != RTX_OK) return rc;
+                if ((rc = upload(dc, p4, &dc->dev.wprims)) != RTX_OK) return rc;
+                if ((rc = upload(dc, w.rank, &dc->dev.wrank)) != RTX_OK) return rc;
+                dc->dev.w_levels = s->w_levels = w.levels;
+                s->w_nodes = (uint32_t)w.n_nodes();
+                s->w_slots = (uint32_t)w.n_slots();
+                s->wide = true;
+            }
         }
     }
 
@@ -641,6 +690,69 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
     hits[i] = out;
 }
 
+// The same contract over the wide form of the fast array: the node step and the primitive tests of
+// render_kernel<..., PK, WIDE>, with the stack of pending groups in private memory.
+// RENDER = false: exact roots and hit record (RTX_TRAVERSAL_FAST_FUSED); true: the render kernels' (RTX_TRAVERSAL_RENDER).
+template <bool RENDER>
+__global__ __launch_bounds__(256) void trace_wide_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
+                                                          rtx_hit_t* __restrict__ hits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SlotReader prims{S.wprims};
+    const uint32_t* __restrict__ rank = S.wrank;
+    Ray r;
+    r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
+    r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
+    r.time = rays[i].time;
+    const RayConst rc = ray_const<SLAB_FMA>(r);
+    Best best;
+    best.t = tmax;
+    best.ent = NO_HIT;
+    uint32_t stack[rtx_accel::WIDE_MAX_LEVELS];
+    uint32_t sp = 0, group = 0, node = 0;
+    for (;;) {
+        const uint4* __restrict__ nd = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.wnodes) + (size_t)node * WIDE_NODE_BYTES);
+        uint32_t next, g, tbase, tmask, n_children;
+        wide_node_step(nd[0], nd[1], nd[2], nd[3], rc, tmin, best.t, next, g, tbase, tmask, n_children);
+        if (g != 0u) {
+            if (group != 0u && sp < rtx_accel::WIDE_MAX_LEVELS) stack[sp++] = group;
+            group = g;
+        }
+        while (tmask != 0u) {
+            const uint32_t k = (uint32_t)__builtin_ctz(tmask);
+            tmask &= tmask - 1u;
+            const uint32_t o = (tbase + k * 5u) * PK_SLOT;
+            const auto slot_at = [&](int q) { return prims.at(o + (uint32_t)q * PK_SLOT); };
+            if (RENDER)
+                pk_render_prim<false>(slot_at(0), slot_at(1), slot_at, o, r, rc, tmin, best, rank);
+            else
+                pk_prim_test<false>(slot_at(0), slot_at(1), slot_at, o, r, rc, tmin, best, rank);
+        }
+        if (next != WIDE_NONE) {
+            node = next;
+            continue;
+        }
+        if (group == 0u && sp != 0u) group = stack[--sp];
+        if (group == 0u) break;
+        node = wide_group_pop(group);
+    }
+    rtx_hit_t out;
+    std::memset(&out, 0, sizeof(out));
+    out.prim_id = RTX_MISS;
+    if (best.ent != NO_HIT) {
+        const uint32_t at = best.ent;
+        const auto slot_at = [&](int k) { return prims.at(at + (uint32_t)k * PK_SLOT); };
+        const HitRec h = RENDER ? pk_render_hit<false, true, true>(S, slot_at, r, best.t) : pk_make_hit<true, true, true>(S, slot_at, r, best.t);
+        out.prim_id = h.prim_id;
+        out.t = best.t;
+        out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
+        out.uv[0] = h.u; out.uv[1] = h.v;
+        out.front_face = 1;  // Hit::new stores `front_face: true` unconditionally (mesh.rs:47)
+        out.p[0] = h.px; out.p[1] = h.py; out.p[2] = h.pz;
+    }
+    hits[i] = out;
+}
+
 extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
                                 void* stream) {
     if (!scene || !opts || (n && (!rays_dev || !hits_dev))) return fail(RTX_ERR_INVALID, "null argument");
@@ -654,11 +766,15 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
         hipLaunchKernelGGL((trace_kernel<true, SLAB_STRICT>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST)
         hipLaunchKernelGGL((trace_kernel<false, SLAB_ROBUST>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
-    else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->packed)  // what the render kernels walk for this scene
+    else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->wide)  // what the render kernels walk for this scene
+        hipLaunchKernelGGL((trace_wide_kernel<false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->packed)
         hipLaunchKernelGGL((trace_packed_kernel<false, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED)
         hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
     // RTX_TRAVERSAL_RENDER: the walk of the render kernel variant a fast render of this scene launches
+    else if (scene->wide)  // render_kernel<false, false, false, *, true, true>: four-child nodes
+        hipLaunchKernelGGL((trace_wide_kernel<true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else if (scene->packed && !scene->pk_half)  // render_kernel<false, true, false, *, true>: float boxes, scaled ray parameters
         hipLaunchKernelGGL((trace_packed_kernel<true, true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else if (scene->packed)  // render_kernel<false, false, false, *, true>: half-precision boxes
@@ -711,15 +827,20 @@ struct RenderParams {
     uint32_t rr_start;
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
+    uint32_t w_mix;       // wide walk: see the walk stage
     uint32_t sched_kp;    // primitive stage keeps running while n_prim * sched_kp >= 8 * lanes queued elsewhere (0 = one step)
     uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
     uint32_t planar_in_lds;  // quad / triangle records (80 bytes each) the launch reserved LDS for, behind the Perlin tables: all of them or 0
     uint32_t n_slots;     // items in flight per wave (tile accumulators per wave): 1 = no overlap of items
+    uint32_t wide_stack_u4;  // WIDE variants: where the block's walk stacks start in LDS, in 16-byte units (behind accumulators and tables)
     uint32_t* item_counter;
     unsigned long long* ray_counter;  // [0] rays, [1] box tests, [2] primitive tests (then diagnostics)
     float* partial;       // [n_batches][H][W][3]
 };
 
+#ifndef RTX_WIDE_WAVES
+#define RTX_WIDE_WAVES 4  // waves per SIMD the wide variants leave registers for
+#endif
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
 constexpr int MAX_WAVES_PER_BLOCK = 16;  // all waves of a block share one LDS copy of the entries; the launch picks 4, 8, 12 or 16
 constexpr int BLOCK_THREADS = 64 * MAX_WAVES_PER_BLOCK;
@@ -738,22 +859,28 @@ extern __shared__ uint4 smem[];
 // the stage most lanes wait for.
 // PK: walk the packed form of the fast array (16-byte slots, half-precision boxes) instead of the 32-byte entries; only
 // for the fast walk of scenes without brackets (!STRICT && !XF).
-template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false>
+// WIDE (with PK, array in HBM): walk the wide form instead -- four-child nodes of one 128-byte line each, primitives in
+// five-slot records, a per-lane stack of pending child groups in LDS.  The box stage becomes the node stage: one step
+// tests the four children of the lane's node, hands the primitives of the leaves it hit to the primitive stage and
+// descends into the nearest child node.
+template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false, bool WIDE = false>
 // Registers per variant, through the waves per SIMD the compiler must leave room for: the lean variants 64 (8 waves), the
 // bracket variants 96 (5 waves: +10 % over 4 on the Cornell scenes, three spilled registers; at 6 they spill 47 and lose
 // 20 %), the texture variants end up at 95 on their own.
-__global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WIDE ? RTX_WIDE_WAVES : 8))) void render_kernel(RenderParams P) {
     static_assert(!PK || (!STRICT && !XF), "the packed array exists for the fast walk of bracket-free scenes only");
+    static_assert(!WIDE || (PK && !ENTS_IN_LDS), "the wide array is walked from HBM in place of the packed one");
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
     constexpr bool SCALED = PK && ENTS_IN_LDS;  // the walk runs in scaled ray parameters (pk_slab_hit_scaled); best.t is scaled too
     const DevScene& S = P.S;
-    const uint4* __restrict__ gents = PK ? S.pk : S.ents[M];
-    const uint32_t* __restrict__ rank = PK ? S.pk_rank : S.rank[M];
+    const uint4* __restrict__ gents = WIDE ? S.wprims : PK ? S.pk : S.ents[M];  // (WIDE: entry offsets are offsets into the primitive records)
+    const uint32_t* __restrict__ rank = WIDE ? S.wrank : PK ? S.pk_rank : S.rank[M];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // what word 3 / word 7 of the entry a lane stands at says about the lane
-    auto at_box = [](uint32_t w) { return PK ? w < PK_PRIM : w == ENT_BOX; };
-    auto at_prim = [](uint32_t w) { return PK ? w - PK_PRIM < ENT_END - PK_PRIM : w - 1u < ENT_END - 1u; };
+    // (WIDE: one walk stage serves the lanes at a node and the lanes at a primitive alike, so every walking lane counts as "box")
+    auto at_box = [](uint32_t w) { return WIDE ? w < ENT_END : PK ? w < PK_PRIM : w == ENT_BOX; };
+    auto at_prim = [](uint32_t w) { return WIDE ? false : PK ? w - PK_PRIM < ENT_END - PK_PRIM : w - 1u < ENT_END - 1u; };
 
     // LDS: [entries incl. terminator (optional)] [per-wave tile accumulators]
     const uint32_t ent_u4 = ENTS_IN_LDS ? (PK ? S.pk_slots : 2u * S.n_ents[M]) : 0u;
@@ -796,6 +923,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     uint32_t rays_traced = 0;  // per lane; summed in 64 bits at the end
     uint32_t wave_box = 0, wave_prim = 0;  // wave-uniform: lanes x steps of the box / primitive stage = tests performed
+    uint32_t lane_box = 0;                 // WIDE: child boxes this lane tested (a node has two to four)
 #ifdef RTX_STAGE_COUNTERS
     unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
     unsigned long long tc[4] = {0, 0, 0, 0};              // wave clocks inside the box / primitive / service stage, and in total
@@ -821,6 +949,27 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
     // XF only: the caller's (world) ray and the bracket state of the walk (transforms, media)
     Ray wray{};
     WalkX wx{};
+    // WIDE only: the node to visit next, the pending group of the deepest level that has one (older groups are on the
+    // lane's stack in LDS, w_sp of them), and the primitives handed out by the last node
+    uint32_t w_node = WIDE_NONE, w_group = 0, w_sp = 0, w_tbase = 0, w_tmask = 0;
+    // stack element k of this lane: dword (k * blockDim.x + threadIdx.x) from the stack base: lanes never share a bank
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t w_stack0 = WIDE ? P.wide_stack_u4 * 16u + threadIdx.x * 4u : 0u;
+    const uint32_t w_stride = blockDim.x * 4u;
+    // the lane's walk moves on to its next node: out of its pending group, else out of the newest group on its stack;
+    // when nothing is pending the walk is complete
+    auto wide_advance = [&]() {
+        if (w_group == 0u && w_sp != 0u) {
+            w_sp--;
+            w_group = *(lds_u32*)(uintptr_t)(w_stack0 + w_sp * w_stride);
+        }
+        if (w_group == 0u) {
+            st = ENT_END;
+        } else {
+            w_node = wide_group_pop(w_group);
+            st = 0u;
+        }
+    };
     const EntReader reader{ENTS_IN_LDS ? reinterpret_cast<const uint4*>(smem) : gents};
 
     // The entries start at LDS address 0 (this kernel has no static LDS, checked below), so a byte offset is already
@@ -867,9 +1016,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
             return v;
         };
     };
-    uint32_t root_st;  // queue of the first entry (wave-uniform)
-    RTX_LOAD_STATE(0u, root_st);
-    root_st = __builtin_amdgcn_readfirstlane(root_st);
+    uint32_t root_st = 0u;  // queue of the first entry (wave-uniform); a wide walk starts at the root node
+    if (!WIDE) {
+        RTX_LOAD_STATE(0u, root_st);
+        root_st = __builtin_amdgcn_readfirstlane(root_st);
+    }
 #define RTX_BEGIN_WALK()                 \
     do {                                 \
         rc = ray_const<SLAB>(ray);       \
@@ -883,6 +1034,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
         rays_traced++;                   \
         off = 0;                         \
         st = root_st;                    \
+        if (WIDE) {                      \
+            w_node = 0u;                 \
+            w_group = 0u;                \
+            w_sp = 0u;                   \
+            w_tmask = 0u;                \
+        }                                \
     } while (0)
 
     // Several items are in flight per wave (P.n_slots of them), each with a tile accumulator of its own.  One, `cur`, still
@@ -983,7 +1140,67 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
                 uint32_t nb = n_box;
                 RTX_TIC();
-                if (PK) {
+                if (WIDE) {
+                    // walk stage: a lane stands at a node (tests its four child boxes) or at a primitive the last node
+                    // handed out (tests it).  Both kinds fetch first -- a node's four slots, a primitive's five, from the
+                    // lane's own address -- and compute after, so one pass pays one trip to memory for every walking lane.
+                    const uint32_t k1 = P.sched_k + 1u;
+                    bool here = at_box(st);
+                    uint32_t tests = 0;
+                    do {
+#ifdef RTX_STAGE_COUNTERS
+                        sc[0]++;
+                        sc[1] += nb;
+#endif
+                        const bool at_node = st == 0u;
+                        // the kind fewer lanes stand at sits a pass out while the other has more than w_mix times as many:
+                        // a wave executes both kinds' code one after the other, whatever the number of lanes in each
+                        const uint32_t n_at_prim = (uint32_t)__popcll(__ballot(here && !at_node)), n_at_node = nb - n_at_prim;
+                        const bool go_node = n_at_node * P.w_mix >= n_at_prim, go_prim = n_at_prim * P.w_mix >= n_at_node;
+                        tests += go_prim ? n_at_prim : 0u;
+                        if (here && (at_node ? go_node : go_prim)) {
+                            const uint32_t prim_i = (uint32_t)__builtin_ctz(w_tmask | 0x80000000u);
+                            const uint32_t prim_o = (w_tbase + prim_i * 5u) * PK_SLOT;
+                            const char* addr = at_node ? reinterpret_cast<const char*>(P.S.wnodes) + (size_t)w_node * WIDE_NODE_BYTES
+                                                       : reinterpret_cast<const char*>(gents) + prim_o;
+                            const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(addr);
+                            const uint4 s0 = rec[0], s1 = rec[1], s2 = rec[2], s3 = rec[3];
+                            uint4 s4;
+                            asm("" : "=v"(s4.x), "=v"(s4.y), "=v"(s4.z), "=v"(s4.w));  // (only lanes at a primitive read it)
+                            if (!at_node) s4 = rec[4];
+                            if (at_node) {
+                                uint32_t next, group, n_children;
+                                wide_node_step(s0, s1, s2, s3, rc, tmin, best.t, next, group, w_tbase, w_tmask, n_children);
+                                lane_box += n_children;
+                                if (group != 0u) {
+                                    if (w_group != 0u) {
+                                        *(lds_u32*)(uintptr_t)(w_stack0 + w_sp * w_stride) = w_group;
+                                        w_sp++;
+                                    }
+                                    w_group = group;
+                                }
+                                w_node = next;
+                                if (w_tmask != 0u) {
+                                    st = PK_PRIM;  // the leaves' primitives first: a hit shortens the interval for the nodes to come
+                                } else if (next == WIDE_NONE) {
+                                    wide_advance();
+                                }
+                            } else {
+                                w_tmask &= w_tmask - 1u;
+                                pk_render_prim<false>(s0, s1, [&](int k) { return k == 2 ? s2 : k == 3 ? s3 : s4; }, prim_o, ray, rc, tmin, best, rank);
+                                if (w_tmask == 0u) {
+                                    if (w_node != WIDE_NONE)
+                                        st = 0u;
+                                    else
+                                        wide_advance();
+                                }
+                            }
+                        }
+                        here = at_box(st);
+                        nb = (uint32_t)__popcll(__ballot(here));
+                    } while (nb * k1 >= n_fixed && nb > 0);
+                    wave_prim += tests;
+                } else if (PK) {
                     // The lane's state word is the box's miss link (in slots).  Arrays in LDS keep float boxes (two slots),
                     // arrays in HBM half-precision ones (one slot).
                     constexpr uint32_t BOX_BYTES = ENTS_IN_LDS ? 2u * PK_SLOT : PK_SLOT;
@@ -1046,7 +1263,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
                     sc[2]++;
                     sc[3] += np;
 #endif
-                    if (PK) {
+                    if (WIDE) {
+                        // (the walk stage tests primitives as well)
+                    } else if (PK) {
                         if (at_prim(st)) {
                             uint4 s0, s1;
                             RTX_LOAD_SLOT(off, s0);
@@ -1256,10 +1475,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : 8)) 
     // launch take longer than a short launch itself.  Every wave leaves its sums in its own accumulator space.
     unsigned long long wave_rays = rays_traced;
     for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
+    unsigned long long wave_lane_box = lane_box;
+    if (WIDE)
+        for (int o = 32; o > 0; o >>= 1) wave_lane_box += __shfl_down(wave_lane_box, o);
     unsigned long long* const tally = reinterpret_cast<unsigned long long*>(acc);
     if (lane == 0) {
         tally[0] = wave_rays;
-        tally[1] = wave_box;
+        tally[1] = WIDE ? wave_lane_box : (unsigned long long)wave_box;
         tally[2] = wave_prim;
     }
     __syncthreads();
@@ -1332,6 +1554,23 @@ static ViewNeed view_need(const rtx_scene* scene, const rtx_camera_t* cam) {
 // copy.  Only the visiting order changes: every trace returns the same hit as before.
 static int order_fast_for_view(rtx_scene* scene, DeviceCopy* c, const float center[3], float grow) {
     if (c->view_valid && std::memcmp(c->view, center, sizeof(c->view)) == 0 && grow == c->view_grow) return RTX_OK;
+    if (scene->wide) {
+        // A wide walk orders the children of a node per ray, so there is nothing to order for a viewpoint; only boxes that
+        // must be enlarged for a distant camera are rebuilt (same tree, same sizes) and uploaded.
+        if (grow != c->wide_grow) {
+            rtx_accel::Wide w;
+            if (!rtx_accel::WideBuilder(scene->fast_indexed, reinterpret_cast<const float*>(scene->planar_host.data()), scene->planar_id_host.data(), scene->n_quads, grow, w).run() ||
+                w.n_nodes() != scene->w_nodes || w.n_slots() != scene->w_slots)
+                return fail(RTX_ERR_DEVICE, "internal: rebuilt wide array changed size");
+            HIP_TRY(hipDeviceSynchronize());  // no walk may be in flight while the nodes are replaced
+            HIP_TRY(hipMemcpy(const_cast<uint4*>(c->dev.wnodes), w.nodes.data(), w.nodes.size() * 4, hipMemcpyHostToDevice));
+            c->wide_grow = grow;
+        }
+        std::memcpy(c->view, center, sizeof(c->view));
+        c->view_grow = grow;
+        c->view_valid = true;
+        return RTX_OK;
+    }
     rtx_accel::Threaded ordered;
     rtx_accel::Reorder(scene->fast_indexed, ordered).run(center, grow);
     rtx_accel::Packed pk;
@@ -1449,6 +1688,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     P.w_prim = K.w_prim;
     P.w_serv = K.w_serv;
     P.sched_kp = K.sched_kp;
+    P.w_mix = std::max(1u, K.w_mix);
 
     const size_t need = npix3 * sizeof(float) * P.n_batches;
     if (scratch->partial_bytes < need) {  // only with may_grow
@@ -1467,6 +1707,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     HIP_TRY(hipMemsetAsync(scratch->counters, 0, COUNTER_BYTES, st));
 
     const bool pk = M == RTX_TRAVERSAL_FAST && scene->packed;  // (a scene with brackets has no packed array)
+    const bool wide = pk && scene->wide && c->dev.wnodes != nullptr;
     const size_t ent_bytes = pk ? (size_t)scene->pk_slots * 16 : (size_t)scene->n_ents[M] * 32;
     // (a packed array has float boxes exactly when it was sized for LDS, and the kernel variants read it accordingly)
     const bool in_lds = pk ? !scene->pk_half : ent_bytes <= K.lds_ents_max;
@@ -1482,7 +1723,10 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     static void (*const packed_kernels[4])(RenderParams) = {
         render_kernel<false, false, false, false, true>, render_kernel<false, false, false, true, true>,
         render_kernel<false, true, false, false, true>,  render_kernel<false, true, false, true, true>};
-    void (*kern)(RenderParams) = pk ? packed_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
+    static void (*const wide_kernels[2])(RenderParams) = {render_kernel<false, false, false, false, true, true>, render_kernel<false, false, false, true, true, true>};
+    if (wide) P.sched_k = K.sched_k_wide;  // (a wide step serves nodes and primitives alike: it pays to leave it for other stages sooner)
+    void (*kern)(RenderParams) = wide ? wide_kernels[scene->has_tex ? 1 : 0]
+                                 : pk ? packed_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
                                     : kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
     // noise textures read their tables 336 times per value: table set 0 goes to LDS (6 KB per block)
@@ -1500,8 +1744,9 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     const uint32_t waves_per_simd = std::max(1u, std::min(8u, 512u / ((vgprs + 7u) & ~7u)));
     uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
     const size_t slot_bytes = SLOT_FLOATS * sizeof(float);
+    const size_t stack_bytes = wide ? (size_t)std::max(1u, scene->w_levels) * 64 * 4 : 0;  // per wave: one dword per lane and level
     for (uint32_t b = 1; b <= (uint32_t)MAX_WAVES_PER_BLOCK / 4; b++) {
-        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * 2 * slot_bytes + perlin_lds + planar_lds;  // with two item slots per wave
+        const size_t l = (in_lds ? ent_bytes : 0) + (size_t)(4 * b) * (2 * slot_bytes + stack_bytes) + perlin_lds + planar_lds;  // with two item slots per wave
         const uint32_t fit = (uint32_t)std::min<size_t>(waves_per_simd / b, (160 * 1024) / (l + 2048));
         if (fit * b >= best_resident && fit > 0) {
             best_resident = fit * b;
@@ -1515,11 +1760,14 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     // items in flight per wave: as many as the LDS left over by that shape holds, two at least
     uint32_t n_slots = 2;
     while (n_slots < K.item_slots &&
-           ((in_lds ? ent_bytes : 0) + (size_t)wpb * (n_slots + 1) * slot_bytes + perlin_lds + planar_lds + 2048) * blocks_per_cu <= 160 * 1024)
+           ((in_lds ? ent_bytes : 0) + (size_t)wpb * ((n_slots + 1) * slot_bytes + stack_bytes) + perlin_lds + planar_lds + 2048) * blocks_per_cu <= 160 * 1024)
         n_slots++;
     if (K.item_slots < 2u) n_slots = K.item_slots;
     P.n_slots = n_slots;
-    const size_t lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * n_slots * slot_bytes + perlin_lds + planar_lds;
+    // (accumulators and tables end on a 16-byte boundary: 784 bytes per slot, 6144 of Perlin tables, 80 per planar record)
+    P.wide_stack_u4 = (uint32_t)(((in_lds ? ent_bytes : 0) + (size_t)wpb * n_slots * slot_bytes + perlin_lds + planar_lds) / 16);
+    const size_t lds = (in_lds ? ent_bytes : 0) + (size_t)wpb * (n_slots * slot_bytes + stack_bytes) + perlin_lds + planar_lds;
+    if (lds > 160 * 1024) return fail(RTX_ERR_DEVICE, "internal: the launch's LDS does not fit");
     dim3 block(64 * wpb), grid((unsigned)std::min<uint64_t>((uint64_t)c->n_cus * blocks_per_cu, ((uint64_t)P.n_items + wpb - 1) / wpb));
     if (K.debug)
         std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u item slots/wave, %u batches of %u spp, %u items\n", vgprs, wpb,
@@ -1554,7 +1802,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         stats->prim_tests = cnt[2];
         stats->kernel_ms = ms;
         stats->n_launches = 1;
-        stats->flags = (in_lds ? 1u : 0u) | (pk ? 2u : 0u);
+        stats->flags = (in_lds ? 1u : 0u) | (pk ? 2u : 0u) | (wide ? 4u : 0u);
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
 #ifdef RTX_STAGE_COUNTERS
         unsigned long long sc[12];
@@ -1715,6 +1963,11 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
         RTX_REBASE(pk_rank);
         if (p.dev.pk_shade) RTX_REBASE(pk_shade);
     }
+    if (p.dev.wnodes) {
+        RTX_REBASE(wnodes);
+        RTX_REBASE(wprims);
+        RTX_REBASE(wrank);
+    }
 #undef RTX_REBASE
     if (scene->n_images != 0) {  // the image table itself holds device pointers
         std::vector<DevImage> im(scene->n_images);
@@ -1730,6 +1983,7 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
     std::memcpy(r->view, p.view, sizeof(r->view));
     r->view_grow = p.view_grow;
     r->view_valid = p.view_valid;
+    r->wide_grow = p.wide_grow;
     HIP_TRY(hipMalloc((void**)&r->counters, COUNTER_BYTES));
     HIP_TRY(hipEventCreate(&r->ev0));
     HIP_TRY(hipEventCreate(&r->ev1));

@@ -593,76 +593,88 @@ __device__ __forceinline__ HitRec pk_render_hit(const DevScene& S, LD ld, const 
 }
 
 // ---------------------------------------------------------------------------------------------- wide fast array
-// One walk step at a four-child node (layout: accel.hpp).  Tests the four child boxes in centre / half-extent form (as
-// pk_slab_hit does for one box) against [tmin, tmax], and reports
+// One walk step at a four-child node (layout: accel.hpp).  Tests the four child boxes against [tmin, tmax] and reports
 //   next   the nearest child node that was hit (WIDE_NONE if none),
-//   group  the other child nodes that were hit, nearest first, as one word:
-//            node index of child 0 << 8 | up to three 2-bit child numbers from bit 2 | how many (bits 0-1); 0 if none
+//   group  the other child nodes that were hit, nearest first, as one word: node index of child 0 << 9 | three 3-bit
+//          entries from bit 0, nearest first -- a child number 0 .. 3, or 7 = no further child; 0 if there is none,
 //   tbase, tmask   the primitives of the leaves that were hit: bit i = the i-th primitive record from slot tbase.
+// A child's box is given on the 256-step grid of the node's own box, one byte per bound.  In ray parameters the planes
+// of axis a lie at q * A_a + B_a with A_a = scale_a / d_a and B_a = (origin_a - o_a) / d_a, one fused multiply-add per
+// plane; which of a child's two bytes is the near plane depends only on the sign of d_a, so it is chosen once per axis
+// for all four children (their bytes share a word).  The rounding of these operations is covered by the padding of the
+// boxes the bytes were rounded outward from, as for the other fused box tests.
 // Children are sorted by the distance at which the ray enters their boxes (ties and the order among leaves do not matter:
-// the closest hit does not depend on the visiting order).  The child number rides in the two low bits of the distance's
+// the closest hit does not depend on the visiting order).  The child number rides in the three low bits of the distance's
 // bit pattern, so sorting four words sorts the children; distances are >= tmin >= 0 in the render kernels, where bit
 // patterns order like the values (a negative tmin in rtx_trace only costs ordering quality, never a hit).
 constexpr uint32_t WIDE_NONE = 0xFFFFFFFFu;
-constexpr uint32_t WIDE_NODE_BYTES = 128u;
+constexpr uint32_t WIDE_NODE_BYTES = 64u;
 constexpr uint32_t WIDE_PRIM_BYTES = 80u;
 
-__device__ __forceinline__ uint32_t wide_child_key(const uint4& c, const uint4& h, const RayConst& rc, float ax, float ay, float az, float tmin,
-                                                   float tmax, uint32_t j) {
-    const float tcx = __builtin_fmaf(as_f(c.x), rc.ix, rc.nx);
-    const float tcy = __builtin_fmaf(as_f(c.y), rc.iy, rc.ny);
-    const float tcz = __builtin_fmaf(as_f(c.z), rc.iz, rc.nz);
-    const float hx = as_f(h.x), hy = as_f(h.y), hz = as_f(h.z);
-    const float enter = fmaxf(fmaxf(__builtin_fmaf(-hx, ax, tcx), __builtin_fmaf(-hy, ay, tcy)), fmaxf(__builtin_fmaf(-hz, az, tcz), tmin));
-    const float exit3 = fminf(fminf(__builtin_fmaf(hx, ax, tcx), __builtin_fmaf(hy, ay, tcy)), __builtin_fmaf(hz, az, tcz));
+template <int J>
+__device__ __forceinline__ float wide_byte(uint32_t w) {  // byte J of w as a float (v_cvt_f32_ubyteJ)
+    return (float)((w >> (8 * J)) & 255u);
+}
+template <int J>
+__device__ __forceinline__ uint32_t wide_child_key(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, float ax, float ay, float az,
+                                                   float bx, float by, float bz, float tmin, float tmax) {
+    const float enter = fmaxf(fmaxf(__builtin_fmaf(wide_byte<J>(nx), ax, bx), __builtin_fmaf(wide_byte<J>(ny), ay, by)),
+                              fmaxf(__builtin_fmaf(wide_byte<J>(nz), az, bz), tmin));
+    const float exit3 = fminf(fminf(__builtin_fmaf(wide_byte<J>(fx), ax, bx), __builtin_fmaf(wide_byte<J>(fy), ay, by)), __builtin_fmaf(wide_byte<J>(fz), az, bz));
     float exit;
     asm("v_min_f32 %0, %1, %2" : "=v"(exit) : "v"(exit3), "v"(tmax));  // (no re-quieting of the interval end, as in slab_hit)
-    return (exit <= enter) ? 0xFFFFFFFFu : ((__float_as_uint(enter) & ~3u) | j);
+    return (exit <= enter) ? 0xFFFFFFFFu : ((__float_as_uint(enter) & ~7u) | (uint32_t)J);
+}
+template <int J>
+__device__ __forceinline__ uint32_t wide_leaf_bits(uint32_t leaves, uint32_t& is_leaf) {  // primitives of leaf J; is_leaf: all ones for a leaf, else 0
+    const uint32_t b = (leaves >> (8 * J)) & 255u;
+    is_leaf = b != 0u ? 0xFFFFFFFFu : 0u;
+    return ((1u << (b >> 5)) - 1u) << (b & 31u);
 }
 
-template <class LD>
-__device__ __forceinline__ void wide_node_step(LD ld, const RayConst& rc, float tmin, float tmax, uint32_t& next, uint32_t& group, uint32_t& tbase,
-                                               uint32_t& tmask, uint32_t& n_children) {
-    const uint4 c0 = ld(0), h0 = ld(1), c1 = ld(2), h1 = ld(3), c2 = ld(4), h2 = ld(5), c3 = ld(6), h3 = ld(7);
-    const uint32_t child_base = c0.w, meta = c1.w;
-    const uint32_t n_int = meta & 7u;
-    const float ax = __builtin_fabsf(rc.ix), ay = __builtin_fabsf(rc.iy), az = __builtin_fabsf(rc.iz);
-    uint32_t k0 = wide_child_key(c0, h0, rc, ax, ay, az, tmin, tmax, 0u);
-    uint32_t k1 = wide_child_key(c1, h1, rc, ax, ay, az, tmin, tmax, 1u);
-    uint32_t k2 = wide_child_key(c2, h2, rc, ax, ay, az, tmin, tmax, 2u);
-    uint32_t k3 = wide_child_key(c3, h3, rc, ax, ay, az, tmin, tmax, 3u);
+// s0 .. s3: the node's four slots
+__device__ __forceinline__ void wide_node_step(const uint4& s0, const uint4& s1, const uint4& s2, const uint4& s3, const RayConst& rc, float tmin, float tmax,
+                                               uint32_t& next, uint32_t& group, uint32_t& tbase, uint32_t& tmask, uint32_t& n_children) {
+    const uint32_t child_base = s0.w, leaves = s2.w;
+    const float ax = as_f(s1.x) * rc.ix, ay = as_f(s1.y) * rc.iy, az = as_f(s1.z) * rc.iz;
+    const float bx = __builtin_fmaf(as_f(s0.x), rc.ix, rc.nx), by = __builtin_fmaf(as_f(s0.y), rc.iy, rc.ny), bz = __builtin_fmaf(as_f(s0.z), rc.iz, rc.nz);
+    // near / far planes per axis for all four children at once
+    const bool px = rc.ix >= 0.0f, py = rc.iy >= 0.0f, pz = rc.iz >= 0.0f;
+    const uint32_t nx = px ? s2.x : s3.x, fx = px ? s3.x : s2.x;
+    const uint32_t ny = py ? s2.y : s3.y, fy = py ? s3.y : s2.y;
+    const uint32_t nz = pz ? s2.z : s3.z, fz = pz ? s3.z : s2.z;
+    uint32_t k0 = wide_child_key<0>(nx, ny, nz, fx, fy, fz, ax, ay, az, bx, by, bz, tmin, tmax);
+    uint32_t k1 = wide_child_key<1>(nx, ny, nz, fx, fy, fz, ax, ay, az, bx, by, bz, tmin, tmax);
+    uint32_t k2 = wide_child_key<2>(nx, ny, nz, fx, fy, fz, ax, ay, az, bx, by, bz, tmin, tmax);
+    uint32_t k3 = wide_child_key<3>(nx, ny, nz, fx, fy, fz, ax, ay, az, bx, by, bz, tmin, tmax);
     // leaves that were hit hand out their primitives
-    const uint32_t n0 = (meta >> 3) & 7u, n1 = (meta >> 6) & 7u, n2 = (meta >> 9) & 7u, n3 = (meta >> 12) & 7u;
-    uint32_t mask = 0u;
-    if (k0 != 0xFFFFFFFFu) mask |= (1u << n0) - 1u;
-    if (k1 != 0xFFFFFFFFu) mask |= ((1u << n1) - 1u) << n0;
-    if (k2 != 0xFFFFFFFFu) mask |= ((1u << n2) - 1u) << (n0 + n1);
-    if (k3 != 0xFFFFFFFFu) mask |= ((1u << n3) - 1u) << (n0 + n1 + n2);
-    tbase = h0.w;
-    tmask = mask;
-    n_children = n_int + (n0 != 0u) + (n1 != 0u) + (n2 != 0u) + (n3 != 0u);
-    // child nodes (children 0 .. n_int - 1) that were hit, nearest first
-    if (0u >= n_int) k0 = 0xFFFFFFFFu;
-    if (1u >= n_int) k1 = 0xFFFFFFFFu;
-    if (2u >= n_int) k2 = 0xFFFFFFFFu;
-    if (3u >= n_int) k3 = 0xFFFFFFFFu;
-    uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
+    uint32_t l0, l1, l2, l3;
+    const uint32_t m0 = wide_leaf_bits<0>(leaves, l0), m1 = wide_leaf_bits<1>(leaves, l1), m2 = wide_leaf_bits<2>(leaves, l2), m3 = wide_leaf_bits<3>(leaves, l3);
+    tbase = s1.w;
+    tmask = (k0 != 0xFFFFFFFFu ? m0 : 0u) | (k1 != 0xFFFFFFFFu ? m1 : 0u) | (k2 != 0xFFFFFFFFu ? m2 : 0u) | (k3 != 0xFFFFFFFFu ? m3 : 0u);
+    n_children = s3.w + (l0 & 1u) + (l1 & 1u) + (l2 & 1u) + (l3 & 1u);
+    // child nodes that were hit, nearest first: a leaf's key becomes all ones like a miss
+    k0 |= l0;
+    k1 |= l1;
+    k2 |= l2;
+    k3 |= l3;
+    const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
     k0 = min(a, c);
-    const uint32_t m1 = max(a, c), m2 = min(b, d);
+    const uint32_t m1s = max(a, c), m2s = min(b, d);
     k3 = max(b, d);
-    k1 = min(m1, m2);
-    k2 = max(m1, m2);
-    const uint32_t hits = (k0 != 0xFFFFFFFFu) + (k1 != 0xFFFFFFFFu) + (k2 != 0xFFFFFFFFu) + (k3 != 0xFFFFFFFFu);
-    next = hits != 0u ? child_base + (k0 & 3u) : WIDE_NONE;
-    group = hits > 1u ? (child_base << 8) | ((k1 & 3u) << 2) | ((k2 & 3u) << 4) | ((k3 & 3u) << 6) | (hits - 1u) : 0u;
+    k1 = min(m1s, m2s);
+    k2 = max(m1s, m2s);
+    next = k0 != 0xFFFFFFFFu ? child_base + (k0 & 3u) : WIDE_NONE;
+    // (a key of all ones leaves 7 = "no further child" in its entry)
+    group = (k1 & 4u) == 0u ? (child_base << 9) | (k1 & 7u) | ((k2 & 7u) << 3) | ((k3 & 7u) << 6) : 0u;
 }
 
 // Takes the next child node out of a pending group: returns its node index and leaves the group with one child fewer
 // (0 when it was the last).  The group must not be 0.
 __device__ __forceinline__ uint32_t wide_group_pop(uint32_t& group) {
-    const uint32_t node = (group >> 8) + ((group >> 2) & 3u);
-    const uint32_t left = (group & 3u) - 1u;
-    group = left != 0u ? ((group & 0xFFFFFF00u) | ((group >> 2) & 0x3Cu) | left) : 0u;
+    const uint32_t node = (group >> 9) + (group & 3u);
+    const uint32_t rest = ((group >> 3) & 0x3Fu) | 0x1C0u;  // the entries move down, "no further child" moves in
+    group = (rest & 4u) == 0u ? ((group & 0xFFFFFE00u) | rest) : 0u;
     return node;
 }
 

@@ -111,7 +111,7 @@ _host = None
 _rtx = None
 
 RTX_SYMBOLS = ["rtx_device_count", "rtx_last_error", "rtx_scene_create", "rtx_scene_destroy", "rtx_trace", "rtx_trace_device",
-               "rtx_render", "rtx_render_multi", "rtx_render_accumulate", "rtx_render_accumulate_static", "rtx_resolve", "rtx_traversal_dump"]
+               "rtx_render", "rtx_render_multi", "rtx_render_accumulate", "rtx_render_accumulate_static", "rtx_resolve", "rtx_traversal_dump", "rtx_wide_dump"]
 
 
 def rtx():
@@ -137,6 +137,8 @@ def rtx():
     L.rtx_resolve.argtypes = [V, C.c_uint32, C.c_uint32, C.c_float, V, V]
     L.rtx_traversal_dump.argtypes = [C.POINTER(SceneDesc), C.c_uint32, capi.c_float_p, C.c_float, capi.c_u32_p, capi.c_u32_p, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
+    L.rtx_wide_dump.argtypes = [C.POINTER(SceneDesc), C.c_float, capi.c_u32_p, C.c_size_t, capi.c_u32_p, capi.c_u32_p, C.c_size_t,
+                                C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
     _rtx = L
     return L
 
@@ -219,6 +221,18 @@ class Scene:
         _check(rtx().rtx_traversal_dump(C.byref(self.desc), traversal, vp, grow, ents.ctypes.data_as(capi.c_u32_p),
                                         rank.ctypes.data_as(capi.c_u32_p), n.value, C.byref(n)))
         return ents, rank
+
+    def wide_dump(self, grow=0.0):
+        """(nodes [n, 16] uint32, prims [slots, 4] uint32, rank [slots] uint32, levels): the wide form of the fast data
+        (host only, no GPU); RtxError(RTX_ERR_UNSUPPORTED) when the scene has none."""
+        nn, ns, lv = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
+        _check(rtx().rtx_wide_dump(C.byref(self.desc), grow, None, 0, None, None, 0, C.byref(nn), C.byref(ns), C.byref(lv)))
+        nodes = np.zeros((nn.value, 16), dtype=np.uint32)
+        prims = np.zeros((ns.value, 4), dtype=np.uint32)
+        rank = np.zeros(ns.value, dtype=np.uint32)
+        _check(rtx().rtx_wide_dump(C.byref(self.desc), grow, nodes.ctypes.data_as(capi.c_u32_p), nn.value, prims.ctypes.data_as(capi.c_u32_p),
+                                   rank.ctypes.data_as(capi.c_u32_p), ns.value, C.byref(nn), C.byref(ns), C.byref(lv)))
+        return nodes, prims, rank, lv.value
 
     def bbox(self):
         out = (C.c_float * 6)()

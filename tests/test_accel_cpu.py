@@ -203,6 +203,112 @@ def walk_packed(slots, rank, ray, half_boxes, tmin=F(0.001)):
     return int(slots[best + 3, 3]), best_t, False, steps
 
 
+def prim_test_packed(fl, slots, i, o, d, a, time, tmin, accept):
+    """Primitive record starting at slot i of a packed / wide primitive array: (t, True) if it is accepted."""
+    kind = int(slots[i, 3]) >> 28
+    if kind == 1:
+        c = [fl[i, k] + fl[i + 1, k] * time for k in range(3)]
+        oc = [c[k] - o[k] for k in range(3)]
+        h = dot3(d[0], d[1], d[2], oc[0], oc[1], oc[2])
+        cc = dot3(oc[0], oc[1], oc[2], oc[0], oc[1], oc[2]) - fl[i + 1, 3] * fl[i + 1, 3]
+        disc = h * h - a * cc
+        if disc < 0:
+            return None
+        sq = np.sqrt(disc)
+        root = (h - sq) / a
+        if not (tmin <= root):
+            root = (h + sq) / a
+        return root if accept(root, i) else None
+    n, q, dd, u, v, w = fl[i, :3], fl[i + 1, :3], fl[i + 1, 3], fl[i + 2, :3], fl[i + 3, :3], fl[i + 4, :3]
+    denom = dot3(n[0], n[1], n[2], d[0], d[1], d[2])
+    if abs(denom) < F(1e-8):
+        return None
+    t = (dd - dot3(n[0], n[1], n[2], o[0], o[1], o[2])) / denom
+    if not accept(t, i):
+        return None
+    p = [(o[k] + d[k] * t) - q[k] for k in range(3)]
+    alpha = dot3(w[0], w[1], w[2], p[1] * v[2] - v[1] * p[2], p[2] * v[0] - v[2] * p[0], p[0] * v[1] - v[0] * p[1])
+    beta = dot3(w[0], w[1], w[2], u[1] * p[2] - p[1] * u[2], u[2] * p[0] - p[2] * u[0], u[0] * p[1] - p[0] * u[1])
+    inside = (alpha >= 0 and beta >= 0 and alpha + beta <= 1) if kind == 3 else (0 <= alpha < 1 and 0 <= beta < 1)
+    return t if inside else None
+
+
+def walk_wide(nodes, prims, rank, levels, ray, tmin=F(0.001)):
+    """Closest hit by walking the wide form: four-child nodes, nearest child node first, pending groups on a stack that
+    never holds more than `levels` groups; returns (prim id or sphere index, t, is_sphere, node steps, primitive tests)."""
+    o = [F(x) for x in ray["o"]]
+    d = [F(x) for x in ray["d"]]
+    time = F(ray["time"])
+    a = dot3(d[0], d[1], d[2], d[0], d[1], d[2])
+    nf, pf = nodes.view(F), prims.view(F)
+    best_t, best = INF, None
+
+    def accept(t, at):
+        if not (tmin <= t):
+            return False
+        if t < best_t:
+            return True
+        return t == best_t and best is not None and rank[at] < rank[best]
+
+    def enter(lo, hi):  # distance at which the ray enters the box [lo, hi], None on a miss (real arithmetic, as packed_box_hit)
+        t0, t1 = float(tmin), float(best_t)
+        for ax in range(3):
+            da = float(d[ax])
+            if abs(da) < 1e-22:
+                da = np.copysign(1e-22, da)
+            ta, tb = (lo[ax] - float(o[ax])) / da, (hi[ax] - float(o[ax])) / da
+            if da < 0:  # the near plane is chosen by the direction's sign (an unused child's inverted box is then never hit)
+                ta, tb = tb, ta
+            t0, t1 = max(t0, ta), min(t1, tb)
+        return None if t1 <= t0 else t0
+
+    stack, node, n_nodes, n_tests = [], 0, 0, 0
+    while node is not None:
+        n_nodes += 1
+        assert n_nodes < 100000, "walk does not terminate"
+        w = nodes[node]
+        origin, scale = nf[node, 0:3].astype(np.float64), nf[node, 4:7].astype(np.float64)
+        child_base, prim_base, leaves, n_int = int(w[3]), int(w[7]), int(w[11]), int(w[15])
+        leaf = [(leaves >> (8 * j)) & 255 for j in range(4)]
+        assert all(leaf[j] == 0 for j in range(n_int)), "a child node has no primitives of its own"
+        hits = []
+        for j in range(4):
+            qlo = np.array([(int(w[8 + a]) >> (8 * j)) & 255 for a in range(3)], dtype=np.float64)
+            qhi = np.array([(int(w[12 + a]) >> (8 * j)) & 255 for a in range(3)], dtype=np.float64)
+            e = enter(origin + scale * qlo, origin + scale * qhi)
+            if j < n_int:
+                if e is not None:
+                    hits.append((e, child_base + j))
+            elif leaf[j]:
+                if e is not None:
+                    for k in range(leaf[j] & 31, (leaf[j] & 31) + (leaf[j] >> 5)):
+                        n_tests += 1
+                        at = prim_base + 5 * k
+                        t = prim_test_packed(pf, prims, at, o, d, a, time, tmin, accept)
+                        if t is not None:
+                            best_t, best = t, at
+            else:
+                assert e is None and np.all(qlo == 255) and np.all(qhi == 0), "an unused child is never hit"
+        hits.sort()
+        if len(hits) > 1:
+            stack.append([n for _, n in hits[1:]])
+            assert len(stack) <= levels, "more pending groups than the tree has levels"
+        if hits:
+            node = hits[0][1]
+        else:
+            node = None
+            while stack and node is None:
+                node = stack[-1].pop(0)
+                if not stack[-1]:
+                    stack.pop()
+    if best is None:
+        return MISS, INF, False, n_nodes, n_tests
+    tag = int(prims[best, 3])
+    if (tag >> 28) == 1:
+        return tag & (PK_PRIM - 1), best_t, True, n_nodes, n_tests
+    return int(prims[best + 3, 3]), best_t, False, n_nodes, n_tests
+
+
 def sample_rays(oracle, cfg, bvh, n_primary, n_secondary, seed):
     capi = importlib.import_module("ray-tracer_amd.capi")
     rng = np.random.default_rng(seed)
@@ -290,3 +396,65 @@ def test_traversal_dump_structure(render, scenes):
         assert len(np.unique(rank[prims])) == hs.n_prims  # one rank per primitive, shared by repeated entries
     with pytest.raises(render.RtxError):
         hs.traversal_dump(7)
+
+
+@pytest.mark.parametrize("name,seed,n_primary,n_secondary", CASES + [("mixed", 2, 100, 80)])
+def test_wide_array_walks_to_the_oracle_hits(render, oracle, scenes, name, seed, n_primary, n_secondary):
+    """The wide form (what the render kernels walk for scenes too large for LDS), built here for small scenes: every
+    primitive is in it exactly once, links stay inside the arrays, and walking it reaches the oracle's hit with a
+    bit-equal t -- also with boxes enlarged for a distant camera -- in fewer steps than the packed array takes."""
+    cfg, bvh = scenes.make(name, seed=seed, width=64, height=36)
+    rays = sample_rays(oracle, cfg, bvh, n_primary, n_secondary, 7)
+    want = oracle.OracleMesh(bvh).trace(rays)
+    hs = render.Scene(bvh, upload=False)
+    sa = SceneArrays(hs.desc)
+    tri_id = _arr(hs.desc.tri_prim_id, hs.desc.n_tris, np.uint32)
+    nodes, prims, rank, levels = hs.wide_dump()
+    n = len(nodes)
+    assert nodes.shape[1] == 16 and prims.shape[0] == 5 * hs.n_prims and 1 <= levels <= 32
+    n_int = nodes[:, 15]
+    leaf = np.stack([(nodes[:, 11] >> (8 * j)) & 255 for j in range(4)], axis=1)
+    counts, starts = leaf >> 5, leaf & 31
+    assert np.all(n_int <= 4) and np.all((nodes[:, 3] + n_int <= n) | (n_int == 0))
+    assert counts.sum() == hs.n_prims and np.all(nodes[:, 7] + 5 * counts.sum(axis=1) <= len(prims))
+    # the leaves of a node share the node's primitives without gaps or overlap, in child order
+    for c, st in zip(counts, starts):
+        run = 0
+        for cj, sj in zip(c.tolist(), st.tolist()):
+            if cj:
+                assert sj == run
+                run += cj
+    children = np.concatenate([nodes[i, 3] + np.arange(n_int[i]) for i in range(n)]) if n else np.zeros(0)
+    assert len(children) == n - 1 and len(np.unique(children)) == n - 1 and (n == 1 or children.min() == 1)  # every node but the root has one parent
+    tags = prims[::5, 3]
+    assert np.all((tags >> 28) >= 1) and np.all((tags >> 28) <= 3)
+    ids = [int(sa.sph_id[t & (PK_PRIM - 1)]) if (t >> 28) == 1 else int(prims[5 * k + 3, 3]) for k, t in enumerate(tags)]
+    assert sorted(ids) == sorted(set(ids)) and len(ids) == hs.n_prims
+    if len(tri_id):
+        assert set(tri_id.tolist()) <= set(ids)
+    os.environ["RTX_PACKED_HALF"] = "1"
+    slots, prank = hs.traversal_dump(render.TRAVERSAL_FAST_FUSED, view=np.asarray(cfg.lookfrom, dtype=F))
+    del os.environ["RTX_PACKED_HALF"]
+    wide_steps = packed_steps = 0
+    for grow in (0.0, 1e-4):
+        if grow:
+            nodes, prims, rank, levels = hs.wide_dump(grow=grow)
+        with np.errstate(all="ignore"):
+            for r, w in zip(rays, want):
+                pid, t, is_sphere, n_nodes, n_tests = walk_wide(nodes, prims, rank, levels, r)
+                if is_sphere:
+                    pid = int(sa.sph_id[pid])
+                assert pid == int(w["prim_id"]), f"{name}/wide: prim {pid} != {int(w['prim_id'])}"
+                if pid != MISS:
+                    assert t == w["t"], f"{name}/wide: t differs"
+                if not grow:
+                    wide_steps += n_nodes + n_tests
+                    packed_steps += walk_packed(slots, prank, r, True)[3]
+    # a step of either walk is one dependent fetch: the wide form needs well under half as many
+    assert wide_steps < 0.6 * packed_steps, (wide_steps / len(rays), packed_steps / len(rays))
+    print(f"[wide] {name}: {n} nodes, {levels} levels, {wide_steps / len(rays):.1f} steps per ray against {packed_steps / len(rays):.1f} over the packed array")
+    # a scene with transforms has no wide form
+    cfg2, bvh2 = scenes.make("cornell-box", seed=0, width=16, height=16)
+    with pytest.raises(render.RtxError) as e:
+        render.Scene(bvh2, upload=False).wide_dump()
+    assert e.value.code == render.RTX_ERR_UNSUPPORTED
