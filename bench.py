@@ -76,6 +76,22 @@ def measured_hbm_traffic(tag):
     return None, None
 
 
+def memory_counters_per_ray(tag):
+    """L2 requests and bytes past L2 per ray of a profiled workload, from the newest committed summary under profiles/
+    (written by scratch/profile_round.sh from rocprofv3 PMC passes of this same command); None when there is none."""
+    import glob
+
+    if tag is None:
+        return None
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_memory_per_ray.json")), reverse=True)
+    for path in paths:
+        with open(path) as f:
+            d = json.load(f)
+        d["source"] = os.path.relpath(path, ROOT)
+        return d
+    return None
+
+
 def self_launch(argv, n):
     """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run from
     this process, which has not touched the GPU, and pass on rank 0's JSON line and the exit code."""
@@ -116,6 +132,9 @@ def main():
     ap.add_argument("--save", default=None, help="write the frame to this PNG (rank 0)")
     ap.add_argument("--work-counts", default=None, help="write the event counts the roofline is priced with (oracle events per sample, "
                                                         "the kernel's own tests of this run) to this JSON file")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the million-triangle block (`secondary.c4`)")
+    ap.add_argument("--rmse-scale", type=int, default=4, help="image_rmse: the frames compared are width/N x height/N of the same camera")
+    ap.add_argument("--rmse-spp", type=int, default=64, help="image_rmse: samples per pixel of the frames compared")
     ap.add_argument("--in-library", action="store_true",
                     help="multi-GPU through the C ABI instead of one process per GPU: ONE process, rtx_render_multi drives --gpus devices")
     args = ap.parse_args()
@@ -160,19 +179,24 @@ def main():
     accum = torch.zeros(n3, device="cuda", dtype=torch.float32)
     rgb = torch.zeros(n3, device="cuda", dtype=torch.uint8)
     stream = torch.cuda.current_stream().cuda_stream
-    if args.split == "tile":
-        begin, end, tile_rank, tile_world = 0, args.spp, rank, world
-    else:
-        (begin, end), tile_rank, tile_world = parallel.sample_range(args.spp, rank, world), 0, 1
+    tile_rank, tile_world = (rank, world) if args.split == "tile" else (0, 1)
     kernel_ms, rays, box_tests, prim_tests, flags = [], [], [], [], []
+    timings = {}
 
     def step(record):
         accum.zero_()
         st = render.Stats()
-        cam.render_accumulate(scene, accum.data_ptr(), begin, end, seed=args.seed, traversal=trav, rr_start_depth=args.rr,
-                              stream=stream, stats=st, tile_rank=tile_rank, tile_world=tile_world)
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+
+        def render_fn(begin, end):  # this rank's share: a sample range of every pixel, or all samples of its tiles
+            cam.render_accumulate(scene, accum.data_ptr(), begin, end, seed=args.seed, traversal=trav, rr_start_depth=args.rr,
+                                  stream=stream, stats=st, tile_rank=tile_rank, tile_world=tile_world)
+            return accum  # (asking for stats synchronises the stream: render_s is the share's device time plus launch)
+
+        parallel.render_split(render_fn, args.spp, rank, world, dist=dist, split=args.split, timings=timings if record else None)
+        if world > 1 and record:
+            t_sync = time.perf_counter()
+            torch.cuda.synchronize()  # the reduce is asynchronous: its device time ends here
+            timings["reduce_s"] += time.perf_counter() - t_sync
         if rank == 0:
             cam.resolve(accum.data_ptr(), rgb.data_ptr(), stream=stream)
         if record:
@@ -196,6 +220,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed, float(sum(rays)), float(sum(box_tests)), float(sum(prim_tests))], device="cuda", dtype=torch.float64)
         tmax = t.clone()
@@ -203,12 +228,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         total_rays, total_box, total_prim = float(t[1]), float(t[2]), float(t[3])
+        # what every rank spent where, so that a scaling curve explains itself: kernel time of its share, host time in the
+        # render call, time in the reduce (which includes waiting for the slowest rank)
+        mine = torch.tensor([float(np.mean(kernel_ms)), timings.get("render_s", 0.0) / args.steps * 1e3, timings.get("reduce_s", 0.0) / args.steps * 1e3],
+                            device="cuda", dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = {"kernel_ms": [round(float(g[0]), 3) for g in gathered], "render_call_ms": [round(float(g[1]), 3) for g in gathered],
+                    "reduce_ms": [round(float(g[2]), 3) for g in gathered]}
     else:
         total_rays, total_box, total_prim = float(sum(rays)), float(sum(box_tests)), float(sum(prim_tests))
 
     if rank == 0:
         parallelism = f"{args.split}-split x{world}, one process per GPU + {'RCCL' if args.backend == 'nccl' else args.backend} reduce" if world > 1 else "single GPU"
         out = result_line(args, cfg, scene.n_prims, world, elapsed, total_rays, total_box, total_prim, float(np.mean(kernel_ms)), parallelism)
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if args.save:
             from PIL import Image
 
@@ -221,7 +256,11 @@ def main():
             out["pcie_inclusive"] = {"value": round(cfg.width * cfg.height * args.spp / dt / 1e6, 2), "unit": "Msamples/s", "ms": round(dt * 1e3, 3),
                                      "note": "one rtx_render call with host buffers: device allocation, render, resolve, RGB8 copied to the host"}
         if world == 1 and not args.no_cpu:
-            cpu_and_roofline(out, args, cfg, bvh, scene, float(np.mean(kernel_ms)), total_rays, total_box, total_prim, bool(flags[-1] & 1), bool(flags[-1] & 2))
+            cpu_and_roofline(out, args, cfg, bvh, scene, float(np.mean(kernel_ms)), total_rays, total_box, total_prim, flags[-1])
+            image_rmse(out, args, cfg, bvh, scene, render, trav)
+            if workload_tag(args) == "c2" and not args.no_secondary:
+                scene.close()  # (frees the device copy of the first scene)
+                out["secondary"] = {"c4": secondary_c4(args, render, scenes, torch)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -254,14 +293,111 @@ def result_line(args, cfg, n_prims, n_gpus, elapsed, total_rays, total_box, tota
     }
 
 
-def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_box, total_prim, entries_in_lds, packed):
-    """CPU baseline (the oracle timed on this box's cores on a bounded sample of the same frame) and the roofline of the
-    dominant kernel from this run's own counts."""
+def workload_tag(args):
+    """"c2" for the default workload, "c4" for the million-triangle configuration: the workloads whose profiles are committed."""
+    key = (args.scene, args.seed, args.width, args.height, args.spp, args.depth, args.traversal, args.rr, args.mesh_nlat)
+    return {("bouncing-spheres", 1, 1920, 1080, 1000, 50, "fast", 0, 0): "c2", ("triangle-mesh", 1, 1920, 1080, 256, 50, "fast", 0, 500): "c4"}.get(key)
+
+
+def host_cores():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+
+
+def image_rmse(out, args, cfg, bvh, scene, render, trav):
+    """The metric's second half: image RMSE against the CPU reference.  A reduced frame of the same scene and camera is
+    rendered by the reference-faithful oracle with two seeds (A, B) and by the GPU with a third; all three are linear fp32
+    radiance means.  RMSE(CPU A, CPU B) is the Monte-Carlo noise floor at this sample count; the GPU frame passes when its
+    RMSE against A stays within 1.25 x that floor and its mean luminance (Rec. 709) within 0.5 % of A's -- or within
+    1.5 x the CPU's own seed-to-seed luminance difference where the estimator is that noisy."""
+    import numpy as np
     from oracle import binding as ob
 
+    w, h, spp = max(16, cfg.width // args.rmse_scale), max(16, cfg.height // args.rmse_scale), args.rmse_spp
+    small = cfg.replace(width=w, height=h, samples_per_pixel=spp)
+    cores = host_cores()
+    print(f"[bench] image RMSE: {w}x{h} at {spp} spp, two oracle frames on {cores} threads ...", file=sys.stderr, flush=True)
+    ob.select("fast")
+    om, oc = ob.OracleMesh(bvh), ob.OracleCamera(small)
+    t0 = time.perf_counter()
+    a = oc.render(om, seed=101, rng_kind=0, threads=cores, want_rgb=False)[0] / spp
+    b = oc.render(om, seed=202, rng_kind=0, threads=cores, want_rgb=False)[0] / spp
+    cpu_s = time.perf_counter() - t0
+    ob.select("checker")
+    g = render.Camera(small).render(scene, seed=303, traversal=trav, rr_start_depth=args.rr, want_accum=True)[1] / spp
+    luma = np.array([0.2126, 0.7152, 0.0722])
+    la, lb, lg = float((a @ luma).mean()), float((b @ luma).mean()), float((g @ luma).mean())
+    r0 = float(np.sqrt(np.mean((a - b) ** 2)))
+    r1 = float(np.sqrt(np.mean((g - a) ** 2)))
+    lum_tol = max(0.005, 1.5 * abs(la - lb) / abs(la))
+    out["image_rmse"] = {
+        "frame": f"{w}x{h} at {spp} spp, linear fp32 radiance means",
+        "gpu_vs_cpu_a": round(r1, 6), "cpu_a_vs_cpu_b": round(r0, 6), "ratio": round(r1 / r0, 4) if r0 > 0 else None,
+        "mean_luminance": {"gpu": round(lg, 6), "cpu_a": round(la, 6), "cpu_b": round(lb, 6), "gpu_vs_cpu_a_rel": round(abs(lg - la) / abs(la), 6),
+                           "tolerance_rel": round(lum_tol, 6)},
+        "pass": bool(r1 <= 1.25 * r0 and abs(lg - la) <= lum_tol * abs(la)),
+        "criterion": "RMSE(GPU, CPU seed A) <= 1.25 x RMSE(CPU seed A, CPU seed B); mean luminance within 0.5 % (or 1.5 x the CPU's own seed-to-seed difference)",
+        "cpu": f"reference-faithful oracle (ChaCha12 stream, rejection samplers), seeds 101 / 202, {cpu_s:.1f} s; GPU seed 303",
+    }
+
+
+def secondary_c4(args, render, scenes, torch):
+    """The million-triangle configuration (triangle-mesh, 998 000 triangles, 1920x1080, 256 spp) measured like the
+    headline workload: one step = one frame, scene resident; with its own roofline (the walk reads its nodes and
+    primitives from HBM / L2: bound "hbm"), CPU baseline and image RMSE, all on reduced CPU frames (the oracle's
+    reference-topology tree tests ~16 000 nodes per ray on this scene)."""
+    import argparse
+    import numpy as np
+
+    a2 = argparse.Namespace(**vars(args))
+    a2.scene, a2.seed, a2.mesh_nlat, a2.spp, a2.width, a2.height = "triangle-mesh", 1, 500, 256, 1920, 1080
+    a2.cpu_scale, a2.cpu_spp, a2.rmse_scale, a2.rmse_spp, a2.work_counts = 8, 4, 20, 16, None
+    print("[bench] secondary workload: building the 998 000-triangle scene ...", file=sys.stderr, flush=True)
+    cfg, bvh = scenes.make(a2.scene, seed=a2.seed, world_args={"n_lat": a2.mesh_nlat}, width=a2.width, height=a2.height,
+                           samples_per_pixel=a2.spp, max_depth=a2.depth)
+    scene, cam = render.Scene(bvh), render.Camera(cfg)
+    trav = render.TRAVERSAL_STRICT if a2.traversal == "strict" else render.TRAVERSAL_FAST
+    n3 = cfg.width * cfg.height * 3
+    accum = torch.zeros(n3, device="cuda", dtype=torch.float32)
+    rgb = torch.zeros(n3, device="cuda", dtype=torch.uint8)
+    stream = torch.cuda.current_stream().cuda_stream
+    stats = []
+
+    def step(record):
+        accum.zero_()
+        st = render.Stats()
+        cam.render_accumulate(scene, accum.data_ptr(), 0, a2.spp, seed=a2.seed, traversal=trav, rr_start_depth=a2.rr, stream=stream, stats=st)
+        cam.resolve(accum.data_ptr(), rgb.data_ptr(), stream=stream)
+        if record:
+            stats.append(st)
+
+    for _ in range(a2.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a2.steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rays, box, prim = (float(sum(getattr(s, k) for s in stats)) for k in ("rays", "box_tests", "prim_tests"))
+    kernel_ms = float(np.mean([s.kernel_ms for s in stats]))
+    out = result_line(a2, cfg, scene.n_prims, 1, elapsed, rays, box, prim, kernel_ms, "single GPU")
+    for k in ("metric", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        del out[k]
+    cpu_and_roofline(out, a2, cfg, bvh, scene, kernel_ms, rays, box, prim, stats[-1].flags)
+    image_rmse(out, a2, cfg, bvh, scene, render, trav)
+    return out
+
+
+def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_box, total_prim, flags):
+    """CPU baseline (the oracle timed on this box's cores on a bounded sample of the same frame) and the roofline of the
+    dominant kernel from this run's own counts.  flags: rtx_stats_t.flags of the timed launches."""
+    from oracle import binding as ob
+
+    entries_in_lds, packed, wide = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+
     samples_per_step = cfg.width * cfg.height * args.spp
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    cores = host_cores()
     # event counts per sample (hits, shades, texture evaluations: the same events whoever traces the rays) from the
     # instrumented build on a 2-spp frame; the TIMED render uses the uninstrumented -O3 build
     cw, ch = max(1, cfg.width // args.cpu_scale), max(1, cfg.height // args.cpu_scale)
@@ -303,8 +439,7 @@ def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_bo
     secs = kernel_ms * 1e-3
     own_tf = own_fps * samples_per_step / secs / 1e12
     ref_tf = ref_fps * samples_per_step / secs / 1e12
-    key = (args.scene, args.seed, args.width, args.height, args.spp, args.depth, args.traversal, args.rr, args.mesh_nlat)
-    tag = {("bouncing-spheres", 1, 1920, 1080, 1000, 50, "fast", 0, 0): "c2", ("triangle-mesh", 1, 1920, 1080, 256, 50, "fast", 0, 500): "c4"}.get(key)
+    tag = workload_tag(args)
     traffic, traffic_file = measured_hbm_traffic(tag)
     valu = {"bound": "valu", "kernel": "render_kernel", "achieved": round(own_tf, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(own_tf / FP32_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_file, "kernel_ms": round(kernel_ms, 3),
@@ -316,17 +451,22 @@ def cpu_and_roofline(out, args, cfg, bvh, scene, kernel_ms, total_rays, total_bo
                                "note": "the same samples priced with the tests the REFERENCE performs (its origin-including boxes make its "
                                        "tree nearly useless): work delivered, which can exceed the peak because the kernel avoids it"}}
     # entries beyond the LDS budget are walked from HBM / L2.  Algorithmic bytes per test, as the kernel lays its data out:
-    #   packed array (no transforms / media):  box 16 B (six halfs + link), sphere 32 B, quad / triangle 80 B, all inline
+    #   wide form (no transforms / media):     a node of 64 B holds up to four child boxes: 16 B per box test; a primitive record 80 B
+    #   packed array (RTX_WIDE=0):             box 16 B (six halfs + link), sphere 32 B, quad / triangle 80 B, all inline
     #   32-byte entries otherwise:             box 32 B, sphere 32 B, quad / triangle 32 B entry + 80 B record
-    box_b, sph_b, planar_b = (16.0, 32.0, 80.0) if packed else (32.0, 32.0, 112.0)
+    box_b, sph_b, planar_b = (16.0, 80.0, 80.0) if wide else (16.0, 32.0, 80.0) if packed else (32.0, 32.0, 112.0)
     rec_bytes = (sph_b * cnt["sphere_tests"] + planar_b * cnt["quad_tests"]) / max(prim_events, 1)
     gbs = (box_b * total_box + rec_bytes * total_prim) / args.steps / secs / 1e9
     hbm = {"bound": "hbm", "kernel": "render_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
-           "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "traffic": traffic, "traffic_source": traffic_file, "kernel_ms": round(kernel_ms, 3),
+           "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "frac_is": "the walk's demand / HBM peak", "traffic": traffic, "traffic_source": traffic_file,
+           "kernel_ms": round(kernel_ms, 3), "layout": "wide" if wide else "packed" if packed else "entries",
            "bytes_per_test": {"box": box_b, "primitive": round(rec_bytes, 1)},
+           "bytes_per_ray": round((box_b * total_box + rec_bytes * total_prim) / max(total_rays, 1.0), 1),
+           "measured_per_ray": memory_counters_per_ray(tag),
            "note": "algorithmic node + primitive bytes of the kernel's own walk (tests counted by the kernel in this run x the bytes "
-                   "one test reads) per launch / kernel time; most of these reads hit L2 or the Infinity Cache, so this is the "
-                   "walk's demand, not DRAM traffic"}
+                   "one test reads) per launch / kernel time; most of these reads hit L1, L2 or the Infinity Cache, so `frac` is the "
+                   "walk's demand over the HBM peak, not an achieved DRAM fraction: the counters under measured_per_ray say where "
+                   "the bytes actually came from"}
     if args.work_counts:
         with open(args.work_counts, "w") as f:
             json.dump({

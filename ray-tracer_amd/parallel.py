@@ -15,15 +15,26 @@ def sample_range(spp: int, rank: int, world: int):
     return (rank * spp) // world, ((rank + 1) * spp) // world
 
 
-def render_split(render_fn, spp: int, rank: int, world: int, dist=None, dst: int = 0):
+def render_split(render_fn, spp: int, rank: int, world: int, dist=None, dst: int = 0, split: str = "spp", timings=None):
     """Render this rank's share with render_fn(begin, end) -> tensor and sum all shares onto `dst`.
 
+    split "spp": the rank's contiguous range of sample indices; "tile": every rank renders all samples (of the tiles it
+    owns -- render_fn knows which), so the sum only puts the tiles together.  `timings` (a dict, optional) receives the
+    wall seconds this rank spent in render_fn ("render_s") and in the reduce ("reduce_s"): both are host times around
+    asynchronous work unless render_fn / the backend synchronise.
     Returns the summed tensor on rank `dst` (other ranks get their own partial back)."""
-    begin, end = sample_range(spp, rank, world)
+    import time
+
+    begin, end = sample_range(spp, rank, world) if split == "spp" else (0, spp)
+    t0 = time.perf_counter()
     accum = render_fn(begin, end)
+    t1 = time.perf_counter()
     if world > 1:
         import torch.distributed as td
 
         d = dist or td
         d.reduce(accum, dst=dst, op=td.ReduceOp.SUM)
+    if timings is not None:
+        timings["render_s"] = timings.get("render_s", 0.0) + (t1 - t0)
+        timings["reduce_s"] = timings.get("reduce_s", 0.0) + (time.perf_counter() - t1)
     return accum
