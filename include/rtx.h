@@ -205,14 +205,17 @@ enum {
                                     hits as FAST for ray origins inside the scene's coordinate range or, after a
                                     render, within the reach of that render's camera: the boxes are padded for that. */
     RTX_TRAVERSAL_RENDER = 3 /* rtx_trace only: every step of the walk through the very functions the kernel of a
-                                    RTX_TRAVERSAL_FAST render of this scene calls -- FAST_FUSED's data, and on top of its
-                                    box test: ray parameters scaled by 2^-60 with the interval start clamped to 0 (float
-                                    boxes), sphere roots and plane distances through the hardware square root and
-                                    reciprocal, normals multiplied by a reciprocal radius.  Hit distances, points and
-                                    normals agree with FAST to a few units in the last place (not bit for bit), ids
-                                    except where two primitives lie within that distance of each other.  It exists so
-                                    that the arithmetic the benchmark times can be checked ray by ray against the
-                                    reference's Sphere::hit / Quad::hit (mesh.rs:113-139, :202-221). */
+                                    RTX_TRAVERSAL_FAST render of this scene calls -- the data that kernel walks (the packed
+                                    form, or the wide form for scenes too large for on-chip memory, or 32-byte entries with
+                                    transforms / media), ray parameters scaled by 2^-60 with the interval start clamped
+                                    to 0 where that kernel does so, and its square roots and quotients: the hardware's
+                                    reciprocal square root / reciprocal plus one Newton step on an exactly computed
+                                    residual.  That lands on the correctly rounded value for all but a vanishing share
+                                    of operands, so hit ids, distances, points and normals equal FAST's bit for bit on
+                                    practically every ray (on every one of ~9 million in the test-suite) -- but it is
+                                    not guaranteed to, which is why the mode exists: the arithmetic the benchmark times
+                                    is checked ray by ray against the reference's Sphere::hit / Quad::hit
+                                    (mesh.rs:113-139, :202-221). */
 };
 
 typedef struct rtx_trace_opts {
@@ -247,7 +250,9 @@ typedef struct rtx_stats {
     double kernel_ms;     /* device time of the path-tracing kernel(s), HIP events on the launch stream */
     double total_ms;      /* wall time of the call */
     uint32_t n_launches;  /* launches of the dominant kernel */
-    uint32_t flags;       /* bit 2: the wide form was walked (four-child nodes of 64 B, primitives of 80 B; see rtx_wide_dump).
+    uint32_t flags;       /* bit 3 (rtx_render_multi): a share's device cannot reach the gathering device directly, so its copies
+                           * were staged through host memory; rtx_last_error() then holds a note naming the devices.
+                           * bit 2: the wide form was walked (four-child nodes of 64 B, primitives of 80 B; see rtx_wide_dump).
                            * bit 0: the traversal entries were resident in LDS (small scene); else walked from HBM / L2.
                            * bit 1: the packed array was walked (16-byte slots: a box is 16 B in HBM, 32 B in LDS; a sphere 32 B;
                            * a quad / triangle 80 B) instead of 32-byte entries with separate 80-byte planar records */
@@ -290,7 +295,16 @@ int rtx_render(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_
  * result into a staging slot on the first listed device over the GPU fabric (hipMemcpyPeerAsync): the fp32 sums,
  * or, for a tile split without accum_out, only its resolved RGB8 bytes.  The first device adds the slots in device
  * order and resolves.  Because the random stream is a function of (seed, pixel, sample index), the frame equals the
- * single-device frame up to the order of fp32 additions (tile split: bit for bit).
+ * single-device frame up to the order of fp32 additions.  (Bit for bit only with a tile split AND one sample per batch
+ * -- a call cuts its sample range into batches of roughly 20 or more samples, so that means a few samples per pixel:
+ * the samples a batch gives one pixel meet in one accumulator in the order their paths finish, which varies from run
+ * to run; which samples a pixel gets, and every sample's value, never do.)
+ * The traversal data is ordered for the camera once, on the scene's own device (one host pass and upload, as in
+ * rtx_render_accumulate); the other devices' copies are brought up to date device to device before any share is
+ * launched, and no share waits for another device at launch.  If a device has no direct (peer) access to the first
+ * one, its copies go through host memory: the call still succeeds, sets bit 3 of stats->flags and leaves a note that
+ * names the devices in rtx_last_error().  A failure after the first share was launched waits for the shares already in
+ * flight before it returns.
  * devices: n_devices HIP device ordinals, or NULL for 0 .. n_devices-1; an ordinal may repeat (several shares on
  * one GPU: a rehearsal of the multi-GPU path on a single-GPU machine).  stats (nullable): samples, rays and test
  * counts are summed over the devices, kernel_ms is the longest device's. */
@@ -308,8 +322,8 @@ int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_r
 int rtx_render_accumulate(rtx_scene_t* scene, const rtx_camera_t* camera, const rtx_render_opts_t* opts,
                           float* accum_dev, void* stream, rtx_stats_t* stats);
 
-/* The same call for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Everything rtx_render_accumulate keeps
+/* The same call for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc;
+ * whether the call can be recorded into a HIP graph has not been tested: it records two timing events on the stream).  It has no counterpart in the reference.  Everything rtx_render_accumulate keeps
  * in library-owned device memory -- the per-batch partial images and the work counters -- lives in one fixed array
  * of RTX_STATIC_SCRATCH_BYTES inside the library's code object (one copy per GPU, held until the process ends), and
  * the call performs no hipMalloc / hipFree and no upload: it fails with RTX_ERR_UNSUPPORTED when

@@ -423,8 +423,11 @@ class Builder {
     }
 
     static constexpr int NBINS = 16;
+    bool bare_leaves = false;  // experiment (RTX_SAH_BARE_LEAF): a leaf of one primitive gets no box of its own
     bool sah(Threaded& out, std::vector<Unit>& units, uint32_t begin, uint32_t end, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
         const float INF = std::numeric_limits<float>::infinity();
+        if (bare_leaves && end - begin == 1 && is_prim(units[begin].ref) && !out.ents.empty())
+            return emit_unit_fast(out, units[begin], false, enclosing_xf, xf_depth, in_medium);
         Box3 bb, cb;
         bb.reset();
         cb.reset();
@@ -502,8 +505,11 @@ class Builder {
             });
             uint32_t mid = (uint32_t)(midit - units.begin());
             if (mid == begin || mid == end) mid = begin + n / 2;
-            out.inner.push_back(at);
-            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium) && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
+            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium);
+            const uint32_t right_at = (uint32_t)out.ents.size();
+            ok = ok && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
+            // (children that may be visited in either order: both must be boxes, whose links say where they end)
+            if (ok && out.ents[at + 1].w[7] == ENT_BOX && right_at < out.ents.size() && out.ents[right_at].w[7] == ENT_BOX) out.inner.push_back(at);
         }
         out.ents[at].w[6] = (uint32_t)out.ents.size();
         return ok;
@@ -1010,6 +1016,7 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     Builder b(d);
     if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) b.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTX_SAH_CTRAV")) b.C_TRAV = (float)std::atof(e);
+    if (const char* e = std::getenv("RTX_SAH_BARE_LEAF")) b.bare_leaves = std::atoi(e) != 0;
     if (!b.emit_strict(strict, d.root, NONE, 0, false)) {
         err = b.err;
         return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;

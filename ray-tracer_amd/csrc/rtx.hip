@@ -65,7 +65,8 @@ static const Knobs& knobs() {
         x.w_serv = std::max(1u, u("RTX_W_SERV", 3));
         x.sched_kp = u("RTX_SCHED_KP", 32);
         x.item_slots = std::min(MAX_ITEM_SLOTS_HOST, std::max(1u, u("RTX_ITEM_SLOTS", 4)));
-        x.lds_ents_max = u("RTX_LDS_ENTS_MAX", 72 * 1024);
+        // (an array in LDS shares the 160 KB with at least one block's accumulators, and has a per-slot shading table)
+        x.lds_ents_max = std::min<uint32_t>(u("RTX_LDS_ENTS_MAX", 72 * 1024), 120 * 1024);
         x.perlin_lds = u("RTX_PERLIN_LDS", 1);
         x.planar_lds_max = u("RTX_PLANAR_LDS_MAX", 16 * 1024);
         x.waves_per_block = u("RTX_WAVES_PER_BLOCK", 0);
@@ -104,6 +105,8 @@ struct DeviceCopy {
     float view_grow = 0.0f;
     bool view_valid = false;
     float wide_grow = 0.0f;  // how far the boxes of this copy's wide nodes are enlarged
+    bool peer_direct = true;  // replica on another device: it can reach the primary's device directly (GPU fabric)
+    std::string peer_note;    // why not, when it cannot
     // rtx_render_multi only: this share's stream, sums and bytes; staging slots on the gathering device
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
@@ -1107,15 +1110,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
                     }
                     live &= ~(1u << k);
                 }
-                if ((wave_box | wave_prim) >= 0x40000000u) {  // keep the 32-bit tallies from wrapping on very long launches
-                    if (lane == 0) {
-                        KArgs* Q = RTX_ARGS();
-                        atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
-                        atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
-                    }
-                    wave_box = 0;
-                    wave_prim = 0;
-                }
                 if (more && live != all_slots) RTX_CLAIM((uint32_t)__builtin_ctz(~live));  // free lanes move on to the next item
                 if (live == 0u) break;  // nothing left anywhere
             }
@@ -1308,6 +1302,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
 #endif
                 KArgs* Q = RTX_ARGS();
                 __attribute__((address_space(4))) const rtx_camera_t& C = Q->cam;
+                // Keep the 32-bit tallies from wrapping, however much work one item holds: checked once per service pass (a
+                // check per box pass costs 3 % on small scenes), between two of which a wave adds at most 64 lanes x one walk
+                // each -- far below the 3e9 of headroom.
+                if ((wave_box | wave_prim) >= 0x40000000u) {
+                    if (lane == 0) {
+                        atomicAdd(Q->ray_counter + 1, (unsigned long long)wave_box);
+                        atomicAdd(Q->ray_counter + 2, (unsigned long long)wave_prim);
+                    }
+                    wave_box = 0;
+                    wave_prim = 0;
+                }
                 bool begin_walk = false;  // scattered and newly generated rays start their walk together, below
                 // what a hit is shaded with (layout: DevScene::shade), indexed like the entries / slots
                 auto shade_rec = [&](uint4& s0, uint4& s1) {
@@ -1600,6 +1605,44 @@ static int order_fast_for_view(rtx_scene* scene, DeviceCopy* c, const float cent
     return RTX_OK;
 }
 
+// Register count of a kernel variant, and the largest dynamic LDS size its launches were enabled for: asked of the runtime
+// once per variant (and device), so that a call in a tight loop makes no attribute queries.
+static std::mutex g_kernel_info_mutex;
+static int kernel_regs(const void* kern, uint32_t* regs_out) {
+    static std::vector<std::pair<const void*, uint32_t>> cache;
+    std::lock_guard<std::mutex> lock(g_kernel_info_mutex);
+    for (const auto& e : cache)
+        if (e.first == kern) {
+            *regs_out = e.second;
+            return RTX_OK;
+        }
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, kern));
+    cache.emplace_back(kern, (uint32_t)std::max(fa.numRegs, 8));
+    *regs_out = cache.back().second;
+    return RTX_OK;
+}
+static int kernel_allow_lds(const void* kern, int device, size_t lds) {
+    struct Entry {
+        const void* kern;
+        int device;
+        size_t lds;
+    };
+    static std::vector<Entry> cache;
+    if (lds <= 48 * 1024) return RTX_OK;
+    std::lock_guard<std::mutex> lock(g_kernel_info_mutex);
+    for (Entry& e : cache)
+        if (e.kern == kern && e.device == device) {
+            if (e.lds >= lds) return RTX_OK;
+            HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            e.lds = lds;
+            return RTX_OK;
+        }
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cache.push_back(Entry{kern, device, lds});
+    return RTX_OK;
+}
+
 // Where a render keeps its library-owned device memory.
 struct Scratch {
     float* partial;        // per-batch partial images
@@ -1738,9 +1781,8 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     // Block shape: a block is 4, 8, 12 or 16 waves (1 to 4 per SIMD).  The variant's register count says how many waves a
     // SIMD can hold (512 VGPRs each, allocated in eights); take the shape that makes the most waves resident within
     // the 160 KB of LDS, and on a tie the larger block (fewer LDS copies of the entries).
-    hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, (const void*)kern));
-    const uint32_t vgprs = (uint32_t)std::max(fa.numRegs, 8);
+    uint32_t vgprs = 0;
+    if ((rc = kernel_regs((const void*)kern, &vgprs)) != RTX_OK) return rc;
     const uint32_t waves_per_simd = std::max(1u, std::min(8u, 512u / ((vgprs + 7u) & ~7u)));
     uint32_t wpb = 4, blocks_per_cu = 1, best_resident = 0;
     const size_t slot_bytes = SLOT_FLOATS * sizeof(float);
@@ -1773,7 +1815,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         std::fprintf(stderr, "[rtx] render_kernel: %u VGPRs, %u waves/block, %u blocks/CU, %zu B LDS/block, %u item slots/wave, %u batches of %u spp, %u items\n", vgprs, wpb,
                      blocks_per_cu, lds, n_slots, P.n_batches, P.batch, P.n_items);
 
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if ((rc = kernel_allow_lds((const void*)kern, c->device, lds)) != RTX_OK) return rc;
 
     HIP_TRY(hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(kern, grid, block, lds, st, P);
@@ -1919,11 +1961,18 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(RTX_ERR_NO_DEVICE, "device is not gfx950");
     r->n_cus = prop.multiProcessorCount;
     if (r->device != p.device) {
+        // direct access to the primary's device makes the copies below (and the share's result on its way back) go over the
+        // GPU fabric; without it the runtime stages them through host memory: slower, still correct -- and reported
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, r->device, p.device) == hipSuccess && can) {
-            hipError_t e = hipDeviceEnablePeerAccess(p.device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies then go through the host
+        hipError_t e = hipDeviceCanAccessPeer(&can, r->device, p.device);
+        if (e == hipSuccess && can) {
+            e = hipDeviceEnablePeerAccess(p.device, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
         }
+        r->peer_direct = e == hipSuccess && can;
+        if (!r->peer_direct)
+            r->peer_note = "device " + std::to_string(r->device) + " has no direct access to device " + std::to_string(p.device) +
+                           (e != hipSuccess ? std::string(" (") + hipGetErrorString(e) + ")" : std::string()) + ": copies are staged through the host";
         (void)hipGetLastError();
     }
     for (const auto& a : p.allocs) {
@@ -1990,6 +2039,36 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
     return RTX_OK;
 }
 
+// Brings a replica's fast traversal data to the order / box sizes the primary's have now: device-to-device copies of the
+// arrays order_fast_for_view rewrites, instead of a second host pass and upload per device.
+static int refresh_replica_order(const rtx_scene* scene, DeviceCopy* r) {
+    const DeviceCopy& p = scene->primary;
+    if (r == &p) return RTX_OK;
+    if (r->view_valid == p.view_valid && std::memcmp(r->view, p.view, sizeof(r->view)) == 0 && r->view_grow == p.view_grow && r->wide_grow == p.wide_grow)
+        return RTX_OK;
+    auto copy = [&](const void* dst, const void* src, size_t bytes) {
+        return bytes == 0 ? hipSuccess : hipMemcpyPeer(const_cast<void*>(dst), r->device, src, p.device, bytes);
+    };
+    const int F = RTX_TRAVERSAL_FAST;
+    if (scene->wide) {
+        HIP_TRY(copy(r->dev.wnodes, p.dev.wnodes, (size_t)scene->w_nodes * rtx_accel::WIDE_NODE_WORDS * 4));
+    } else {
+        if (scene->packed) {
+            HIP_TRY(copy(r->dev.pk, p.dev.pk, (size_t)scene->pk_slots * 16));
+            HIP_TRY(copy(r->dev.pk_rank, p.dev.pk_rank, (size_t)scene->pk_slots * 4));
+            if (p.dev.pk_shade) HIP_TRY(copy(r->dev.pk_shade, p.dev.pk_shade, (size_t)scene->pk_slots * 32));
+        }
+        HIP_TRY(copy(r->dev.ents[F], p.dev.ents[F], (size_t)scene->n_ents[F] * 32));
+        HIP_TRY(copy(r->dev.rank[F], p.dev.rank[F], (size_t)scene->n_ents[F] * 4));
+        HIP_TRY(copy(r->dev.shade[F], p.dev.shade[F], (size_t)scene->n_ents[F] * 32));
+    }
+    std::memcpy(r->view, p.view, sizeof(r->view));
+    r->view_grow = p.view_grow;
+    r->view_valid = p.view_valid;
+    r->wide_grow = p.wide_grow;
+    return RTX_OK;
+}
+
 __global__ __launch_bounds__(256) void add_slots_kernel(float* __restrict__ dst, const float* __restrict__ slots, uint32_t n_slots, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2038,10 +2117,22 @@ extern "C" int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* cam, con
         ~Restore() { hipSetDevice(d); }
     } restore{prev};
 
+    // The fast traversal data is prepared for this camera ONCE, on the primary (host pass + upload), before any replica is
+    // made or refreshed: replicas then take it over device to device, and no share prepares anything at launch.
+    uint32_t M = opts->traversal;
+    if (M > RTX_TRAVERSAL_STRICT) return fail(RTX_ERR_INVALID, "unknown traversal mode");
+    if (M == RTX_TRAVERSAL_FAST) {
+        const ViewNeed need = view_need(scene, cam);
+        if (!need.strict_only && (knobs().view_order != 0u || need.grow > 0.0f)) {
+            HIP_TRY(hipSetDevice(scene->primary.device));
+            if ((rc = order_fast_for_view(scene, &scene->primary, cam->center, need.grow)) != RTX_OK) return rc;
+        }
+    }
     // share k runs on copy k: the primary when it lives on the share's device and no earlier share took it
     if (scene->replicas.size() < n_devices) scene->replicas.resize(n_devices, nullptr);
     std::vector<DeviceCopy*> copy(n_devices, nullptr);
     bool primary_taken = false;
+    std::string notes;
     for (uint32_t k = 0; k < n_devices; k++) {
         HIP_TRY(hipSetDevice(dev[k]));
         if (!primary_taken && dev[k] == scene->primary.device) {
@@ -2066,6 +2157,8 @@ extern "C" int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* cam, con
                     return rc;
                 }
             }
+            if ((rc = refresh_replica_order(scene, r)) != RTX_OK) return rc;
+            if (!r->peer_direct && notes.find(r->peer_note) == std::string::npos) notes += (notes.empty() ? "" : "; ") + r->peer_note;
             copy[k] = r;
         }
         DeviceCopy* c = copy[k];
@@ -2079,11 +2172,30 @@ extern "C" int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* cam, con
     const size_t slot_bytes = bytes_only ? n : n * sizeof(float);
     if (n_devices > 1 && (rc = ensure_buffer((char**)&root->staging, &root->staging_bytes, slot_bytes * (n_devices - 1))) != RTX_OK) return rc;
 
-    // launch every share on its own device and stream, then push its result into its slot on the first device
-    std::vector<rtx_stats_t> st(n_devices);
+    // From the first launch on, a failure must not return while earlier shares' kernels and copies are still in flight: they
+    // write into buffers the scene owns and the next call reuses.
+    uint32_t launched = 0;
+    auto bail = [&](int code) {
+        const std::string keep = g_err;
+        for (uint32_t k = 0; k < launched && k < n_devices; k++) {
+            if (hipSetDevice(dev[k]) == hipSuccess) (void)hipStreamSynchronize(copy[k]->stream);
+        }
+        (void)hipGetLastError();
+        g_err = keep;
+        return code;
+    };
+#define MULTI_TRY(expr)                                                                                              \
+    do {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess) return bail(fail(RTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+
+    // launch every share on its own device and stream (nothing here waits for a device), then push its result into its
+    // slot on the first device
     for (uint32_t k = 0; k < n_devices; k++) {
         DeviceCopy* c = copy[k];
-        HIP_TRY(hipSetDevice(dev[k]));
+        MULTI_TRY(hipSetDevice(dev[k]));
+        launched = k + 1;
         rtx_render_opts_t o = *opts;
         o.n_gpus = 0;
         if (split == RTX_SPLIT_SAMPLES) {
@@ -2097,40 +2209,43 @@ extern "C" int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* cam, con
             o.tile_rank = k;
             o.tile_world = n_devices;
         }
-        HIP_TRY(hipMemsetAsync(c->accum, 0, n * sizeof(float), c->stream));
-        HIP_TRY(hipMemsetAsync(c->counters, 0, COUNTER_BYTES, c->stream));  // a share with nothing to render launches nothing
+        MULTI_TRY(hipMemsetAsync(c->accum, 0, n * sizeof(float), c->stream));
+        MULTI_TRY(hipMemsetAsync(c->counters, 0, COUNTER_BYTES, c->stream));  // a share with nothing to render launches nothing
         Scratch scratch{c->partial, c->partial_bytes, c->counters, true};
-        if ((rc = render_accumulate_on(scene, c, cam, &o, c->accum, c->stream, nullptr, &scratch, true)) != RTX_OK) return rc;
+        if ((rc = render_accumulate_on(scene, c, cam, &o, c->accum, c->stream, nullptr, &scratch, false)) != RTX_OK) return bail(rc);
         if (bytes_only) {
-            if ((rc = rtx_resolve(c->accum, cam->width, cam->height, cam->pixel_samples_scale, c->rgb, c->stream)) != RTX_OK) return rc;
-            if (k > 0) HIP_TRY(hipMemcpyPeerAsync((char*)root->staging + (size_t)(k - 1) * slot_bytes, dev[0], c->rgb, dev[k], slot_bytes, c->stream));
+            if ((rc = rtx_resolve(c->accum, cam->width, cam->height, cam->pixel_samples_scale, c->rgb, c->stream)) != RTX_OK) return bail(rc);
+            if (k > 0) MULTI_TRY(hipMemcpyPeerAsync((char*)root->staging + (size_t)(k - 1) * slot_bytes, dev[0], c->rgb, dev[k], slot_bytes, c->stream));
         } else if (k > 0) {
-            HIP_TRY(hipMemcpyPeerAsync((char*)root->staging + (size_t)(k - 1) * slot_bytes, dev[0], c->accum, dev[k], slot_bytes, c->stream));
+            MULTI_TRY(hipMemcpyPeerAsync((char*)root->staging + (size_t)(k - 1) * slot_bytes, dev[0], c->accum, dev[k], slot_bytes, c->stream));
         }
-        HIP_TRY(hipEventRecord(c->done, c->stream));
+        MULTI_TRY(hipEventRecord(c->done, c->stream));
     }
     // the first device waits for every slot, combines them in device order and resolves
-    HIP_TRY(hipSetDevice(dev[0]));
-    for (uint32_t k = 1; k < n_devices; k++) HIP_TRY(hipStreamWaitEvent(root->stream, copy[k]->done, 0));
+    MULTI_TRY(hipSetDevice(dev[0]));
+    for (uint32_t k = 1; k < n_devices; k++) MULTI_TRY(hipStreamWaitEvent(root->stream, copy[k]->done, 0));
     {
         dim3 b(256), g((unsigned)((n + 255) / 256));
         if (bytes_only) {
             if (n_devices > 1) {
                 hipLaunchKernelGGL(merge_tiles_kernel, g, b, 0, root->stream, root->rgb, (const uint8_t*)root->staging, n_devices, n, cam->width,
                                    (cam->width + TILE - 1) / TILE);
-                HIP_TRY(hipGetLastError());
+                MULTI_TRY(hipGetLastError());
             }
         } else {
             if (n_devices > 1) {
                 hipLaunchKernelGGL(add_slots_kernel, g, b, 0, root->stream, root->accum, (const float*)root->staging, n_devices - 1, n);
-                HIP_TRY(hipGetLastError());
+                MULTI_TRY(hipGetLastError());
             }
-            if ((rc = rtx_resolve(root->accum, cam->width, cam->height, cam->pixel_samples_scale, root->rgb, root->stream)) != RTX_OK) return rc;
+            if ((rc = rtx_resolve(root->accum, cam->width, cam->height, cam->pixel_samples_scale, root->rgb, root->stream)) != RTX_OK) return bail(rc);
         }
     }
-    HIP_TRY(hipMemcpyAsync(rgb8_out, root->rgb, n, hipMemcpyDeviceToHost, root->stream));
-    if (accum_out) HIP_TRY(hipMemcpyAsync(accum_out, root->accum, n * sizeof(float), hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(hipStreamSynchronize(root->stream));
+    MULTI_TRY(hipMemcpyAsync(rgb8_out, root->rgb, n, hipMemcpyDeviceToHost, root->stream));
+    if (accum_out) MULTI_TRY(hipMemcpyAsync(accum_out, root->accum, n * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+    MULTI_TRY(hipStreamSynchronize(root->stream));
+#undef MULTI_TRY
+    // (a share that cannot reach the first device directly still delivered its result, through the host: say so)
+    if (!notes.empty()) g_err = "note: " + notes;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         for (uint32_t k = 0; k < n_devices; k++) {
@@ -2151,6 +2266,7 @@ extern "C" int rtx_render_multi(rtx_scene_t* scene, const rtx_camera_t* cam, con
             stats->n_launches += 1;
         }
         stats->samples = (uint64_t)cam->width * cam->height * spp;
+        stats->flags = notes.empty() ? 0u : 8u;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     }
     return RTX_OK;

@@ -40,6 +40,10 @@ pub const RTX_TEX_NOISE: u32 = 3;
 
 pub const RTX_TRAVERSAL_FAST: u32 = 0;
 pub const RTX_TRAVERSAL_STRICT: u32 = 1;
+/// rtx_trace / rtx_traversal_dump only: the fast data as the render kernels walk it, exact primitive arithmetic.
+pub const RTX_TRAVERSAL_FAST_FUSED: u32 = 2;
+/// rtx_trace only: every step through the functions the render kernels call.
+pub const RTX_TRAVERSAL_RENDER: u32 = 3;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -214,7 +218,8 @@ pub struct rtx_stats_t {
     pub kernel_ms: f64,
     pub total_ms: f64,
     pub n_launches: u32,
-    /// bit 0: the traversal entries were resident in LDS
+    /// bit 0: the traversal entries were resident in LDS; bit 1: packed array; bit 2: wide form; bit 3 (rtx_render_multi): a
+    /// share's copies were staged through the host (no peer access), see rtx_last_error()
     pub flags: u32,
     pub box_tests: u64,
     pub prim_tests: u64,
@@ -240,11 +245,22 @@ extern "C" {
                             n_devices: u32, split: u32, rgb8_out: *mut u8, accum_out: *mut f32, stats: *mut rtx_stats_t) -> c_int;
     pub fn rtx_render_accumulate(scene: *mut rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, accum_dev: *mut f32,
                                  stream: *mut c_void, stats: *mut rtx_stats_t) -> c_int;
+    /// rtx_render_accumulate for callers that cannot allocate device memory: its scratch lives in a fixed array of
+    /// RTX_STATIC_SCRATCH_BYTES inside the library (one per GPU); RTX_ERR_UNSUPPORTED for frames beyond it and for cameras
+    /// the fast data was not prepared for.  Calls that overlap on one GPU race.
+    pub fn rtx_render_accumulate_static(scene: *mut rtx_scene_t, camera: *const rtx_camera_t, opts: *const rtx_render_opts_t, accum_dev: *mut f32,
+                                        stream: *mut c_void, stats: *mut rtx_stats_t) -> c_int;
     pub fn rtx_resolve(accum_dev: *const f32, width: u32, height: u32, scale: f32, rgb8_dev: *mut u8, stream: *mut c_void) -> c_int;
     /// Host-only inspection of the traversal data (no device is touched).
     pub fn rtx_traversal_dump(desc: *const rtx_scene_desc_t, traversal: u32, view: *const f32, grow: f32, entries_out: *mut u32, rank_out: *mut u32,
                               capacity: usize, n_entries: *mut usize) -> c_int;
+    /// Host-only inspection of the wide form (four-child nodes of 64 bytes, five-slot primitive records).
+    pub fn rtx_wide_dump(desc: *const rtx_scene_desc_t, grow: f32, nodes_out: *mut u32, node_capacity: usize, prims_out: *mut u32, rank_out: *mut u32,
+                         slot_capacity: usize, n_nodes: *mut usize, n_slots: *mut usize, levels: *mut u32) -> c_int;
 }
+
+/// Size of the fixed scratch array of rtx_render_accumulate_static.
+pub const RTX_STATIC_SCRATCH_BYTES: u32 = 64 << 20;
 
 /// Text of the last failure on this thread.
 pub fn last_error() -> String {

@@ -108,6 +108,9 @@ def test_bench_two_ranks_render_the_single_rank_frame(tmp_path, split):
         assert d["n_gpus"] == n and d["unit"] == "Msamples/s" and d["value"] > 0 and d["scaling"] == "strong"
         assert d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
         assert d["box_tests_per_ray"] > 1 and d["prim_tests_per_ray"] > 0.1
+        if n == 2:  # every rank's kernel, render-call and reduce time, so that a scaling curve explains itself
+            pr = d["per_rank"]
+            assert len(pr["kernel_ms"]) == len(pr["render_call_ms"]) == len(pr["reduce_ms"]) == 2 and min(pr["kernel_ms"]) > 0
     # the same two shares behind the C ABI: one process, rtx_render_multi
     three = tmp_path / "three.png"
     out3 = subprocess.check_output([sys.executable, "bench.py", "--gpus", "2", "--in-library", "--one-device", "--split", split, "--save", str(three)]

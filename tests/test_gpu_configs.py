@@ -248,6 +248,22 @@ def test_render_multi_equals_single_device(render, scenes, name, seed):
     assert e.value.code == render.RTX_ERR_NO_DEVICE
 
 
+def test_render_multi_follows_the_camera(render, scenes):
+    """The fast data is ordered for a camera once, on the scene's own device, and the other shares' copies are brought up
+    to date device to device: a second camera on the far side of the scene (and farther out: its boxes are enlarged), then
+    the first again, each time the single-device frame -- and a trace afterwards still finds the same hits."""
+    cfg, bvh = scenes.make("bouncing-spheres", seed=1, width=160, height=96, samples_per_pixel=6)
+    scene = render.Scene(bvh)
+    cams = [render.Camera(cfg), render.Camera(cfg.replace(lookfrom=tuple(-3.0 * float(c) for c in cfg.lookfrom))), render.Camera(cfg)]
+    for k, cam in enumerate(cams):
+        single = cam.render(scene, seed=8, want_accum=True)[1]
+        rgb_t, acc_t, st = cam.render(scene, seed=8, want_accum=True, want_stats=True, devices=[0, 0, 0], split=render.SPLIT_TILES)
+        assert np.array_equal(acc_t, single), k  # one sample per batch: bit for bit
+        assert st.flags & 8 == 0  # every share sits on the gathering device
+        acc_s = cam.render(scene, seed=8, want_accum=True, devices=[0, 0], split=render.SPLIT_SAMPLES)[1]
+        assert np.allclose(acc_s, single, rtol=1e-5, atol=1e-5), k
+
+
 def test_work_counters_and_stats(render, scenes):
     """The kernel's own test counts come back with the stats: plausible, repeatable, and they respond to the traversal."""
     cfg, bvh = scenes.make("bouncing-spheres", seed=1, width=160, height=90, samples_per_pixel=8)
