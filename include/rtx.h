@@ -61,7 +61,11 @@ enum {
     RTX_OBJ_LIST = 0,      /* World / Cube (mesh.rs:54-101, :259-322): linear closest-hit scan of refs[first .. first+count) */
     RTX_OBJ_TRANSLATE = 1, /* mesh.rs:324-354: child, f[0..3] = offset                               */
     RTX_OBJ_ROTATE_Y = 2,  /* mesh.rs:356-432: child, f[0] = sin_theta, f[1] = cos_theta              */
-    RTX_OBJ_MEDIUM = 3     /* mesh.rs:627-696: child = boundary, f[0] = density, material = Isotropic, prim_id */
+    RTX_OBJ_MEDIUM = 3     /* mesh.rs:627-696: child = boundary, f[0] = density, material = Isotropic, prim_id.
+                            * Narrower than the reference: the boundary may be any hittable EXCEPT one that contains
+                            * another RTX_OBJ_MEDIUM (the reference's `B: Mesh` would accept that, none of its scenes
+                            * builds it); rtx_scene_create refuses such a scene with RTX_ERR_UNSUPPORTED -- the walk
+                            * keeps one level of saved boundary-query state per ray. */
 };
 typedef struct rtx_object {
     uint32_t kind;
@@ -242,7 +246,20 @@ typedef struct rtx_render_opts {
     uint32_t n_gpus;                   /* rtx_render only: 0 or 1 = the scene's device; N > 1 = devices 0..N-1, driven
                                           from this one call (see rtx_render_multi) */
     uint32_t split;                    /* rtx_render with n_gpus > 1: RTX_SPLIT_* */
+    uint32_t flags;                    /* RTX_RENDER_* */
 } rtx_render_opts_t;
+
+/* rtx_render_opts_t.flags */
+enum {
+    RTX_RENDER_REPRODUCIBLE = 1 /* Two calls with the same arguments return the same bits, whatever the sample count.
+                                   By default a wave works on several (tile, sample batch) items at once, so the order
+                                   in which the samples of one pixel are added depends on which items the wave happened
+                                   to get before: frames agree to the order of fp32 additions only.  With this flag a
+                                   wave finishes one item before it starts the next; what it then does is a function of
+                                   the item alone.  Costs about 6 % on the benchmark scene (lanes idle while an item
+                                   drains).  The reference itself is not reproducible at all (thread_rng), so this has
+                                   no counterpart there. */
+};
 
 typedef struct rtx_stats {
     uint64_t samples;     /* pixel samples rendered by the call */

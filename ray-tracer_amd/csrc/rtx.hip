@@ -1158,10 +1158,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
                             const char* addr = at_node ? reinterpret_cast<const char*>(P.S.wnodes) + (size_t)w_node * WIDE_NODE_BYTES
                                                        : reinterpret_cast<const char*>(gents) + prim_o;
                             const uint4* __restrict__ rec = reinterpret_cast<const uint4*>(addr);
-                            const uint4 s0 = rec[0], s1 = rec[1], s2 = rec[2], s3 = rec[3];
-                            uint4 s4;
+                            const uint4 s0 = rec[0], s1 = rec[1];
+                            uint4 s2 = rec[2], s3 = rec[3], s4;
                             asm("" : "=v"(s4.x), "=v"(s4.y), "=v"(s4.z), "=v"(s4.w));  // (only lanes at a primitive read it)
                             if (!at_node) s4 = rec[4];
+                            // (whole slots in one load each: left to itself the compiler fetches the words only node lanes
+                            // read with loads of their own, and the walk is bound by the number of vector memory instructions)
+                            asm("" : "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w), "+v"(s3.x), "+v"(s3.y), "+v"(s3.z), "+v"(s3.w));
                             if (at_node) {
                                 uint32_t next, group, n_children;
                                 wide_node_step(s0, s1, s2, s3, rc, tmin, best.t, next, group, w_tbase, w_tmask, n_children);
@@ -1805,6 +1808,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
            ((in_lds ? ent_bytes : 0) + (size_t)wpb * ((n_slots + 1) * slot_bytes + stack_bytes) + perlin_lds + planar_lds + 2048) * blocks_per_cu <= 160 * 1024)
         n_slots++;
     if (K.item_slots < 2u) n_slots = K.item_slots;
+    if ((opts->flags & RTX_RENDER_REPRODUCIBLE) != 0u) n_slots = 1;  // one item at a time: a wave's adds depend on the item alone
     P.n_slots = n_slots;
     // (accumulators and tables end on a 16-byte boundary: 784 bytes per slot, 6144 of Perlin tables, 80 per planar record)
     P.wide_stack_u4 = (uint32_t)(((in_lds ? ent_bytes : 0) + (size_t)wpb * n_slots * slot_bytes + perlin_lds + planar_lds) / 16);

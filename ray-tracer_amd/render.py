@@ -23,6 +23,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 
 TRAVERSAL_FAST, TRAVERSAL_STRICT, TRAVERSAL_FAST_FUSED, TRAVERSAL_RENDER = 0, 1, 2, 3
 SPLIT_SAMPLES, SPLIT_TILES = 0, 1
+RENDER_REPRODUCIBLE = 1
 RTX_OK, RTX_ERR_INVALID, RTX_ERR_UNSUPPORTED, RTX_ERR_DEVICE, RTX_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 
@@ -51,7 +52,8 @@ class RenderOpts(C.Structure):
     """rtx_render_opts_t"""
 
     _fields_ = [("seed", C.c_uint64), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("traversal", C.c_uint32),
-                ("rr_start_depth", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("n_gpus", C.c_uint32), ("split", C.c_uint32)]
+                ("rr_start_depth", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("n_gpus", C.c_uint32), ("split", C.c_uint32),
+                ("flags", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -287,7 +289,7 @@ class Camera:
         return d
 
     def render(self, scene, seed=0, traversal=TRAVERSAL_FAST, rr_start_depth=0, want_accum=False, want_stats=False, n_gpus=1,
-               split=SPLIT_SAMPLES, devices=None):
+               split=SPLIT_SAMPLES, devices=None, reproducible=False):
         """Whole-frame render through rtx_render (host buffers). Returns rgb8 [H,W,3] (+ accum [H,W,3] f32 sums, + Stats).
         n_gpus > 1: the one call drives GPUs 0 .. n_gpus-1; devices=[...] names them explicitly (rtx_render_multi; an
         ordinal may repeat to rehearse the multi-GPU path on one GPU)."""
@@ -296,12 +298,12 @@ class Camera:
         accum = np.zeros((h, w, 3), dtype=F) if want_accum else None
         st = Stats()
         if devices is not None:
-            opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth)
+            opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth, 0, 0, 0, 0, RENDER_REPRODUCIBLE if reproducible else 0)
             ids = (C.c_int * len(devices))(*devices)
             _check(rtx().rtx_render_multi(scene.device, C.byref(self.ffi), C.byref(opts), ids, len(devices), split, rgb.ctypes.data,
                                           accum.ctypes.data if want_accum else None, C.byref(st)))
         else:
-            opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth, 0, 0, n_gpus, split)
+            opts = RenderOpts(seed, 0, 0, traversal, rr_start_depth, 0, 0, n_gpus, split, RENDER_REPRODUCIBLE if reproducible else 0)
             _check(rtx().rtx_render(scene.device, C.byref(self.ffi), C.byref(opts), rgb.ctypes.data,
                                     accum.ctypes.data if want_accum else None, C.byref(st)))
         out = [rgb]
@@ -312,11 +314,12 @@ class Camera:
         return out[0] if len(out) == 1 else tuple(out)
 
     def render_accumulate(self, scene, accum_ptr, sample_begin, sample_end, seed=0, traversal=TRAVERSAL_FAST, rr_start_depth=0,
-                          stream=None, stats=None, tile_rank=0, tile_world=1, static=False):
+                          stream=None, stats=None, tile_rank=0, tile_world=1, static=False, reproducible=False):
         """rtx_render_accumulate on a device buffer (3*W*H f32) for the sample range [sample_begin, sample_end) of the
         tiles t with t % tile_world == tile_rank.  static=True: rtx_render_accumulate_static, the variant that keeps its
         scratch in a fixed device array and allocates nothing."""
-        opts = RenderOpts(seed, sample_begin, sample_end, traversal, rr_start_depth, tile_rank, tile_world)
+        opts = RenderOpts(seed, sample_begin, sample_end, traversal, rr_start_depth, tile_rank, tile_world, 0, 0,
+                          RENDER_REPRODUCIBLE if reproducible else 0)
         fn = rtx().rtx_render_accumulate_static if static else rtx().rtx_render_accumulate
         _check(fn(scene.device, C.byref(self.ffi), C.byref(opts), accum_ptr, stream,
                                            C.byref(stats) if stats is not None else None))

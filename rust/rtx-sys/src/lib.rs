@@ -205,7 +205,13 @@ pub struct rtx_render_opts_t {
     pub n_gpus: u32,
     /// RTX_SPLIT_SAMPLES (0) or RTX_SPLIT_TILES (1) when n_gpus > 1.
     pub split: u32,
+    /// RTX_RENDER_* bits.
+    pub flags: u32,
 }
+
+/// rtx_render_opts_t.flags: two calls with the same arguments return the same bits (a wave finishes one work item before
+/// it starts the next; about 6 % slower on the benchmark scene).
+pub const RTX_RENDER_REPRODUCIBLE: u32 = 1;
 
 pub const RTX_SPLIT_SAMPLES: u32 = 0;
 pub const RTX_SPLIT_TILES: u32 = 1;

@@ -156,6 +156,16 @@ def test_repeat_runs_at_benchmark_batch_sizes(render, scenes):
         one.append(buf)
     torch.cuda.synchronize()
     assert torch.equal(one[0], one[1])
+    # RTX_RENDER_REPRODUCIBLE: the same bits at any sample count (a wave finishes one item before it starts the next), and
+    # the same frame as the default schedule up to the order of additions
+    rep = []
+    for _ in range(3):
+        buf = torch.zeros(n, device="cuda")
+        cam.render_accumulate(scene, buf.data_ptr(), 0, 640, seed=11, stream=st, reproducible=True)
+        rep.append(buf)
+    torch.cuda.synchronize()
+    assert torch.equal(rep[0], rep[1]) and torch.equal(rep[0], rep[2])
+    assert float(((rep[0] - a).abs() / scale).max()) < 2e-5
 
 
 def test_sample_range_zero_zero_renders_nothing(render, scenes):
