@@ -48,7 +48,7 @@ constexpr uint32_t MAX_ITEM_SLOTS_HOST = 8;  // items in flight per wave, upper 
 // Tuning knobs, read from the environment once per process.
 struct Knobs {
     uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, planar_lds_max, perlin_lds, waves_per_block,
-        blocks_per_cu, debug, wide, w_mix, sched_k_wide;
+        blocks_per_cu, debug, wide, w_mix, sched_k_wide, xcd_items;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -75,6 +75,7 @@ static const Knobs& knobs() {
         x.wide = u("RTX_WIDE", 1);
         x.w_mix = u("RTX_W_MIX", 3);
         x.sched_k_wide = std::max(1u, u("RTX_SCHED_K_WIDE", 3));
+        x.xcd_items = u("RTX_XCD_ITEMS", 1);
         return x;
     }();
     return k;
@@ -82,6 +83,7 @@ static const Knobs& knobs() {
 
 // ================================================================================================ scene
 constexpr size_t COUNTER_BYTES = 256;
+constexpr uint32_t XCD_COUNTER_AT = 48;  // dword index of the eight per-XCD item counters inside the counter block (behind the tallies)
 constexpr size_t PK_SHADE_TABLE_MAX_BYTES = 160 * 1024;  // packed arrays up to this size (any that can live in LDS) get a per-slot shading table
 
 static bool env_flag(const char* name, bool dflt) {
@@ -835,6 +837,7 @@ struct RenderParams {
     uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
     uint32_t planar_in_lds;  // quad / triangle records (80 bytes each) the launch reserved LDS for, behind the Perlin tables: all of them or 0
     uint32_t n_slots;     // items in flight per wave (tile accumulators per wave): 1 = no overlap of items
+    uint32_t xcd_parts;   // scenes in HBM: 0 = one item counter, 1 = a counter per band of tile columns, 2 = per range of owned tiles
     uint32_t wide_stack_u4;  // WIDE variants: where the block's walk stacks start in LDS, in 16-byte units (behind accumulators and tables)
     uint32_t* item_counter;
     unsigned long long* ray_counter;  // [0] rays, [1] box tests, [2] primitive tests (then diagnostics)
@@ -1059,20 +1062,67 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
     const uint32_t n_slots = P.n_slots, all_slots = (1u << n_slots) - 1u;
     uint32_t* const item_hdr = reinterpret_cast<uint32_t*>(acc + n_slots * ACC_FLOATS);  // [slot][4]: tile origin, batch
 
+    // Packed or wide arrays walked from HBM (the large scenes): each XCD has an L2 of its own, so items are handed out per XCD from eight parts of the image
+    // (bands of tile columns; contiguous ranges of the owned tiles when the call renders a strided share of them), each
+    // with a counter of its own: the waves of an XCD work next to each other in the image, and what their rays read stays
+    // in that XCD's L2 instead of being fetched into all eight (million-triangle mesh: 17 % fewer L2 misses; the frame
+    // time does not change, since that walk is bound by instruction issue).  A part that runs out sends its waves on to
+    // the next part (they join its owners at the front of its counter), so the parts need not be equal in work.
+    auto claim_near = [&](KArgs* q, uint32_t& tx, uint32_t& ty, uint32_t& batch) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+#pragma unroll 1
+        for (uint32_t i = 0; i < 8u; i++) {
+            const uint32_t part = (xcc + i) & 7u;
+            const bool cols = q->xcd_parts == 1u;
+            const uint32_t span = cols ? q->tiles_x : q->n_owned;            // what is cut into eight
+            const uint32_t lo = part * span / 8u, hi = (part + 1u) * span / 8u;
+            const uint32_t part_tiles = cols ? (hi - lo) * q->tiles_y : hi - lo;
+            if (part_tiles == 0u) continue;
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(q->item_counter + XCD_COUNTER_AT + part, 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= part_tiles * q->n_batches) continue;
+            batch = k / part_tiles;
+            const uint32_t r = k % part_tiles;
+            if (cols) {
+                tx = lo + r % (hi - lo);
+                ty = r / (hi - lo);
+            } else {
+                const uint32_t tile = q->tile_rank + (lo + r) * q->tile_world;
+                tx = tile % q->tiles_x;
+                ty = tile / q->tiles_x;
+            }
+            return true;
+        }
+        return false;
+    };
+
 #define RTX_CLAIM(k)                                                                                             \
     do {                                                                                                         \
         KArgs* q_ = RTX_ARGS();                                                                                  \
-        uint32_t item_ = 0;                                                                                      \
-        if (lane == 0) item_ = atomicAdd(q_->item_counter, 1u);                                                  \
-        item_ = __builtin_amdgcn_readfirstlane(item_);                                                           \
-        if (item_ >= q_->n_items) {                                                                              \
+        uint32_t item_ = 0, tx_ = 0, ty_ = 0, batch_ = 0;                                                        \
+        bool got_ = false;                                                                                       \
+        if (PK && !ENTS_IN_LDS && q_->xcd_parts != 0u) {                                                         \
+            got_ = claim_near(q_, tx_, ty_, batch_);                                                             \
+        } else {                                                                                                 \
+            if (lane == 0) item_ = atomicAdd(q_->item_counter, 1u);                                              \
+            item_ = __builtin_amdgcn_readfirstlane(item_);                                                       \
+            if (item_ < q_->n_items) {                                                                           \
+                const uint32_t tile_ = q_->tile_rank + (item_ % q_->n_owned) * q_->tile_world;                   \
+                got_ = true;                                                                                     \
+                batch_ = item_ / q_->n_owned;                                                                    \
+                tx_ = tile_ % q_->tiles_x;                                                                       \
+                ty_ = tile_ / q_->tiles_x;                                                                       \
+            }                                                                                                    \
+        }                                                                                                        \
+        if (!got_) {                                                                                             \
             more = false;                                                                                        \
         } else {                                                                                                 \
-            const uint32_t tile_ = q_->tile_rank + (item_ % q_->n_owned) * q_->tile_world;                       \
             cur = (k);                                                                                           \
             live |= 1u << cur;                                                                                   \
-            cur_batch = __builtin_amdgcn_readfirstlane(item_ / q_->n_owned);                                     \
-            cur_txy = __builtin_amdgcn_readfirstlane(((tile_ % q_->tiles_x) * TILE) | (((tile_ / q_->tiles_x) * TILE) << 16)); \
+            cur_batch = __builtin_amdgcn_readfirstlane(batch_);                                                  \
+            cur_txy = __builtin_amdgcn_readfirstlane((tx_ * TILE) | ((ty_ * TILE) << 16));                        \
             pool_total = __builtin_amdgcn_readfirstlane(64u * min(q_->batch, q_->sample_end - (q_->sample_begin + cur_batch * q_->batch))); \
             pool_next = 0;                                                                                       \
             acc[cur * ACC_FLOATS + lane] = 0.0f;                                                                 \
@@ -1770,6 +1820,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         render_kernel<false, false, false, false, true>, render_kernel<false, false, false, true, true>,
         render_kernel<false, true, false, false, true>,  render_kernel<false, true, false, true, true>};
     static void (*const wide_kernels[2])(RenderParams) = {render_kernel<false, false, false, false, true, true>, render_kernel<false, false, false, true, true, true>};
+    P.xcd_parts = K.xcd_items == 0u ? 0u : (P.tile_world == 1u ? 1u : 2u);
     if (wide) P.sched_k = K.sched_k_wide;  // (a wide step serves nodes and primitives alike: it pays to leave it for other stages sooner)
     void (*kern)(RenderParams) = wide ? wide_kernels[scene->has_tex ? 1 : 0]
                                  : pk ? packed_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
