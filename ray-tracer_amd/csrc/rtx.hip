@@ -976,7 +976,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
             st = 0u;
         }
     };
-    const EntReader reader{ENTS_IN_LDS ? reinterpret_cast<const uint4*>(smem) : gents};
+    const typename std::conditional<ENTS_IN_LDS, EntReaderLds, EntReader>::type reader = [&] {
+        if constexpr (ENTS_IN_LDS)
+            return EntReaderLds{};
+        else
+            return EntReader{gents};
+    }();
 
     // The entries start at LDS address 0 (this kernel has no static LDS, checked below), so a byte offset is already
     // the LDS address of an entry and no base needs adding per load.

@@ -699,12 +699,22 @@ __device__ __forceinline__ void walkx_init(WalkX& x, float tmin) {
     x.med_t1 = __builtin_nanf("");
 }
 
-struct EntReader {  // reads entries through a generic pointer (LDS or global); used on the rare bracket paths
+struct EntReader {  // reads entries of an array in global memory by byte offset (the bracket paths, hit records)
     const uint4* base;
     __device__ __forceinline__ void load(uint32_t off, uint4& a, uint4& b) const {
         const char* p = reinterpret_cast<const char*>(base) + off;
         a = *reinterpret_cast<const uint4*>(p);
         b = *reinterpret_cast<const uint4*>(p + 16);
+    }
+};
+struct EntReaderLds {  // the same for a copy of the array that starts at LDS address 0: a byte offset is the LDS address
+    __device__ __forceinline__ void load(uint32_t off, uint4& a, uint4& b) const {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const u32x4 lds_u4;
+        lds_u4* p = (lds_u4*)(uintptr_t)off;
+        const u32x4 a_ = p[0], b_ = p[1];
+        a = make_uint4(a_.x, a_.y, a_.z, a_.w);
+        b = make_uint4(b_.x, b_.y, b_.z, b_.w);
     }
 };
 
@@ -729,7 +739,8 @@ __device__ __forceinline__ void xf_apply(const uint4& ea, Ray& r) {
 // An entry only links to its parent, so the chain is walked once to count it and then once per level from the top;
 // nesting is shallow (two levels in the reference's scenes), and any depth the host accepts works.
 constexpr int XF_MAX_DEPTH = 64;  // the host rejects deeper nesting (rtx_accel::MAX_XF_DEPTH)
-__device__ inline Ray xf_chain_ray(const EntReader& ents, uint32_t xf, const Ray& w) {
+template <class READER>
+__device__ inline Ray xf_chain_ray(const READER& ents, uint32_t xf, const Ray& w) {
     Ray r = w;
     if (xf == XF_NONE) return r;
     uint4 a, b;
@@ -759,8 +770,8 @@ __device__ inline Ray xf_chain_ray(const EntReader& ents, uint32_t xf, const Ray
 
 // One walk step at a bracket entry (ea, eb) at byte offset off.  `ray` is the ray in the current frame, `wray` the
 // caller's ray; `main_tmin` the start of the caller's interval; the caller's interval end is the running best.
-template <bool STRICT, int SLAB>
-__device__ inline void bracket_step(const EntReader& ents, const uint4& ea, const uint4& eb, uint32_t& off, Ray& ray, RayConst& rc, const Ray& wray,
+template <bool STRICT, int SLAB, class READER>
+__device__ inline void bracket_step(const READER& ents, const uint4& ea, const uint4& eb, uint32_t& off, Ray& ray, RayConst& rc, const Ray& wray,
                                     Best& best, WalkX& x, float main_tmin, Rng& rng, const uint32_t* __restrict__ rank) {
     const uint32_t kind = eb.w & 15u;
     if (kind == ENT_XF_PUSH) {
@@ -832,8 +843,8 @@ __device__ inline void bracket_step(const EntReader& ents, const uint4& ea, cons
 // frame, then carry point and normal out through the enclosing transforms as the reference does -- Translate adds its
 // offset to the point (mesh.rs:334); RotateY re-applies its FORWARD rotation and reads the already overwritten x
 // (mesh.rs:378-382).
-template <bool WANT_UV, bool EXACT>
-__device__ inline HitRec make_hit_x(const DevScene& S, const EntReader& ents, const Ray& wray, const Best& best, uint32_t best_xf) {
+template <bool WANT_UV, bool EXACT, class READER>
+__device__ inline HitRec make_hit_x(const DevScene& S, const READER& ents, const Ray& wray, const Best& best, uint32_t best_xf) {
     uint4 ha, hb;
     ents.load(best.ent, ha, hb);
     const Ray lr = xf_chain_ray(ents, best_xf, wray);
