@@ -38,6 +38,15 @@
 namespace rtx_accel {
 
 enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3, ENT_XF_PUSH = 4, ENT_XF_POP = 5, ENT_MED_BEGIN = 6, ENT_MED_END = 7 };
+// Fast arrays only: ENT_INST | ENT_SPHERE / ENT_QUAD / ENT_TRI is a primitive of a Translate / RotateY instance placed in
+// the tree of the enclosing frame under a box of its own (in that frame's coordinates) instead of behind the
+// instance's brackets.  The entry is the primitive's own (object space) with the index of its chain record in a spare
+// word -- w[3] of a sphere (only spheres that do not move are placed this way), w[1] of a quad / triangle; the test moves
+// the ray into object space through the chain, operation for operation what the bracket entries would have done, so
+// hits are the same bit for bit.  A chain record is one entry behind the terminator: two levels of (kind 1 = translate
+// | 2 = rotate-y | 0 = none, three parameters), outermost first.
+constexpr uint32_t ENT_INST = 8;
+constexpr int MAX_INST_LEVELS = 2;
 constexpr uint32_t ENT_END = 0xFFFFFFFEu;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int MAX_XF_DEPTH = 64;  // nested Translate / RotateY levels accepted (the kernels walk the chain of enclosing transforms)
@@ -54,6 +63,7 @@ struct Threaded {
     uint32_t n_boxes = 0, n_prims = 0;
     bool has_brackets = false;   // contains transform or medium entries
     std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
+    std::vector<Ent> chains;     // fast only: chain records of the ENT_INST entries (appended behind the terminator by finalize)
 };
 
 static inline uint32_t fbits(float f) {
@@ -158,6 +168,7 @@ struct Unit {  // something a fast tree places under a leaf box: a primitive or 
     Box3 box;
     rtx_ref_t ref;
     uint32_t rank;
+    uint32_t chain = 0xFFFFFFFFu;  // primitive of an instance placed in the enclosing frame: its chain record
 };
 
 class Builder {
@@ -304,6 +315,53 @@ class Builder {
     }
 
     // ------------------------------------------------------------------------------------------ fast
+    // Bounds, in the enclosing frame, of a box given in the frame of a Translate / RotateY object.
+    static Box3 xf_box(const rtx_object_t& o, const Box3& c) {
+        Box3 out;
+        out.reset();
+        if (o.kind == RTX_OBJ_TRANSLATE) {
+            for (int a = 0; a < 3; a++) { out.lo[a] = c.lo[a] + o.f[a]; out.hi[a] = c.hi[a] + o.f[a]; }
+        } else {
+            // object -> world rotation of the eight corners (mesh.rs:405-423)
+            const float s = o.f[0], co = o.f[1];
+            for (int ci = 0; ci < 8; ci++) {
+                float x = (ci & 1) ? c.hi[0] : c.lo[0], y = (ci & 2) ? c.hi[1] : c.lo[1], z = (ci & 4) ? c.hi[2] : c.lo[2];
+                float p[3] = {co * x + s * z, y, -s * x + co * z};
+                for (int a = 0; a < 3; a++) { out.lo[a] = std::fmin(out.lo[a], p[a]); out.hi[a] = std::fmax(out.hi[a], p[a]); }
+            }
+            float m = out.max_abs();
+            for (int a = 0; a < 3; a++) { out.lo[a] -= 1e-6f * m; out.hi[a] += 1e-6f * m; }
+        }
+        return out;
+    }
+
+    // Instances whose primitives are placed in the enclosing frame's tree (ENT_INST): a Translate / RotateY, at most
+    // MAX_INST_LEVELS of them nested, over nothing but primitives (spheres at rest), lists and Bvh nodes.
+    bool place_instances = true;
+    std::vector<std::vector<uint32_t>> inst_chains;  // per chain record: its objects, outermost first
+    bool flattenable(rtx_ref_t r, int levels, int guard = 0) {
+        if (guard > 4096 || !check_ref(r)) return false;
+        const uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
+        if (k == RTX_REF_NODE) return flattenable(d.bvh_nodes[i].left, levels, guard + 1) && flattenable(d.bvh_nodes[i].right, levels, guard + 1);
+        if (k == RTX_REF_SPHERE) return d.sph_dx[i] == 0.0f && d.sph_dy[i] == 0.0f && d.sph_dz[i] == 0.0f;
+        if (is_prim(r)) return true;
+        const rtx_object_t& o = d.objects[i];
+        if (o.kind == RTX_OBJ_LIST) {
+            if ((uint64_t)o.first + o.count > d.n_refs) return false;
+            for (uint32_t c = 0; c < o.count; c++)
+                if (!flattenable(d.refs[o.first + c], levels, guard + 1)) return false;
+            return true;
+        }
+        if (o.kind == RTX_OBJ_TRANSLATE || o.kind == RTX_OBJ_ROTATE_Y) return levels < MAX_INST_LEVELS && flattenable(o.child, levels + 1, guard + 1);
+        return false;
+    }
+    uint32_t chain_id(const std::vector<uint32_t>& objs) {
+        for (uint32_t c = 0; c < inst_chains.size(); c++)
+            if (inst_chains[c] == objs) return c;
+        inst_chains.push_back(objs);
+        return (uint32_t)inst_chains.size() - 1u;
+    }
+
     // Local-space bounds of everything under a reference (tight; padding is applied per unit).
     bool bounds_of(rtx_ref_t r, Box3& out_box, int guard = 0) {
         if (!check_ref(r)) return false;
@@ -331,18 +389,8 @@ class Builder {
                 Box3 c;
                 if (!bounds_of(o.child, c, guard + 1)) return false;
                 coord_range = std::fmax(coord_range, 2.0f * c.max_abs());
-                if (o.kind == RTX_OBJ_TRANSLATE) {
-                    for (int a = 0; a < 3; a++) { out_box.lo[a] = c.lo[a] + o.f[a]; out_box.hi[a] = c.hi[a] + o.f[a]; }
-                } else if (o.kind == RTX_OBJ_ROTATE_Y) {
-                    // object -> world rotation of the eight corners (mesh.rs:405-423)
-                    const float s = o.f[0], co = o.f[1];
-                    for (int ci = 0; ci < 8; ci++) {
-                        float x = (ci & 1) ? c.hi[0] : c.lo[0], y = (ci & 2) ? c.hi[1] : c.lo[1], z = (ci & 4) ? c.hi[2] : c.lo[2];
-                        float p[3] = {co * x + s * z, y, -s * x + co * z};
-                        for (int a = 0; a < 3; a++) { out_box.lo[a] = std::fmin(out_box.lo[a], p[a]); out_box.hi[a] = std::fmax(out_box.hi[a], p[a]); }
-                    }
-                    float m = out_box.max_abs();
-                    for (int a = 0; a < 3; a++) { out_box.lo[a] -= 1e-6f * m; out_box.hi[a] += 1e-6f * m; }
+                if (o.kind == RTX_OBJ_TRANSLATE || o.kind == RTX_OBJ_ROTATE_Y) {
+                    out_box = xf_box(o, c);
                 } else if (o.kind == RTX_OBJ_MEDIUM) {
                     out_box = c;
                 } else {
@@ -355,27 +403,42 @@ class Builder {
     }
 
     // Units under a reference: BVH nodes and lists are dissolved, primitives and bracketed objects are kept whole.
-    bool collect_units(rtx_ref_t r, std::vector<Unit>& units, int guard = 0) {
+    // may_place: instances met here may have their primitives placed in this frame's tree (top-level frame only: the
+    // chain then starts from the caller's ray); chain: the instances already entered on the way, outermost first.
+    bool collect_units(rtx_ref_t r, std::vector<Unit>& units, bool may_place, int guard = 0, std::vector<uint32_t>* chain = nullptr) {
         if (!check_ref(r)) return false;
         if (guard > 4096) return fail("scene graph too deep (cycle?)");
         uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
         if (k == RTX_REF_NODE) {
             const rtx_bvh_node_t& n = d.bvh_nodes[i];
-            if (!collect_units(n.left, units, guard + 1)) return false;
-            return n.right == n.left || collect_units(n.right, units, guard + 1);
+            if (!collect_units(n.left, units, may_place, guard + 1, chain)) return false;
+            return n.right == n.left || collect_units(n.right, units, may_place, guard + 1, chain);
         }
         if (k == RTX_REF_OBJECT && d.objects[i].kind == RTX_OBJ_LIST) {
             const rtx_object_t& o = d.objects[i];
             if ((uint64_t)o.first + o.count > d.n_refs) return fail("list object exceeds refs");
             for (uint32_t c = 0; c < o.count; c++)
-                if (!collect_units(d.refs[o.first + c], units, guard + 1)) return false;
+                if (!collect_units(d.refs[o.first + c], units, may_place, guard + 1, chain)) return false;
             return true;
+        }
+        if (k == RTX_REF_OBJECT && (d.objects[i].kind == RTX_OBJ_TRANSLATE || d.objects[i].kind == RTX_OBJ_ROTATE_Y) && may_place && place_instances &&
+            flattenable(r, chain ? (int)chain->size() : 0)) {
+            std::vector<uint32_t> inner = chain ? *chain : std::vector<uint32_t>();
+            inner.push_back(i);
+            Box3 c;
+            if (!bounds_of(r, c)) return false;  // (validates the subtree and feeds coord_range as for a bracketed instance)
+            return collect_units(d.objects[i].child, units, may_place, guard + 1, &inner);
         }
         Unit u;
         u.ref = r;
         auto it = first_rank.find(r);
         u.rank = it == first_rank.end() ? 0u : it->second;
         if (!bounds_of(r, u.box)) return false;
+        if (chain != nullptr && !chain->empty()) {
+            for (size_t l = chain->size(); l-- > 0;) u.box = xf_box(d.objects[(*chain)[l]], u.box);  // innermost level first
+            if (!u.box.valid()) return fail("NaN in object bounds");
+            u.chain = chain_id(*chain);
+        }
         units.push_back(u);
         return true;
     }
@@ -387,11 +450,13 @@ class Builder {
 
     bool emit_fast_subtree(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
         std::vector<Unit> units;
-        if (!collect_units(r, units)) return false;
+        if (!collect_units(r, units, enclosing_xf == NONE)) return false;
         if (units.empty()) return fail("empty subtree");
         // drop duplicates (a one-element Bvh lists its child twice, shared objects may repeat): keep the first by rank
-        std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.ref != b.ref ? a.ref < b.ref : a.rank < b.rank; });
-        units.erase(std::unique(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.ref == b.ref; }), units.end());
+        std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) {
+            return a.ref != b.ref ? a.ref < b.ref : a.chain != b.chain ? a.chain < b.chain : a.rank < b.rank;
+        });
+        units.erase(std::unique(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.ref == b.ref && a.chain == b.chain; }), units.end());
         std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.rank < b.rank; });
         for (Unit& u : units) {
             coord_range_seen = std::fmax(coord_range_seen, u.box.max_abs());
@@ -404,6 +469,12 @@ class Builder {
     bool emit_unit_fast(Threaded& out, const Unit& u, bool guard_box, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
         if (is_prim(u.ref)) {
             push_prim(out, u.ref, u.rank);
+            if (u.chain != NONE) {
+                Ent& e = out.ents.back();
+                e.w[7] |= ENT_INST;
+                e.w[RTX_REF_KIND(u.ref) == RTX_REF_SPHERE ? 3 : 1] = u.chain;
+                out.has_brackets = true;  // rendered by the variants that know transforms
+            }
             return true;
         }
         const rtx_object_t& o = d.objects[RTX_REF_INDEX(u.ref)];
@@ -543,6 +614,7 @@ class Reorder {
         dst.n_boxes = src.n_boxes;
         dst.n_prims = src.n_prims;
         dst.has_brackets = src.has_brackets;
+        dst.chains = src.chains;
         dst.inner.clear();
         for (uint32_t j = 0; j < n;) j = place(j, view);
         // links that name an entry (not the end of the own subtree) go through the index map
@@ -1009,6 +1081,19 @@ static inline void finalize(Threaded& t) {
     t.ents.push_back(end);
     t.rank.push_back(0);
     t.mat.push_back(NONE);
+    // chain records of the ENT_INST entries go behind the terminator, where no walk comes by; the entries name them by byte offset
+    const uint32_t chains_at = (uint32_t)t.ents.size();
+    for (uint32_t i = 0; i + 1 < chains_at; i++) {
+        Ent& e = t.ents[i];
+        if (e.w[7] == ENT_BOX || (e.w[7] & ENT_INST) == 0u) continue;
+        uint32_t& c = e.w[(e.w[7] & 3u) == ENT_SPHERE ? 3 : 1];
+        c = (chains_at + c) * S;
+    }
+    for (const Ent& c : t.chains) {
+        t.ents.push_back(c);
+        t.rank.push_back(0);
+        t.mat.push_back(NONE);
+    }
 }
 
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.
@@ -1032,9 +1117,20 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     }
     b.coord_range = std::fmax(b.coord_range, world.max_abs());
     if (!std::isfinite(b.coord_range)) { err = "non-finite scene bounds"; return RTX_ERR_INVALID; }
+    if (const char* e = std::getenv("RTX_PLACE_INSTANCES")) b.place_instances = std::atoi(e) != 0;
     if (!b.emit_fast_subtree(fast, d.root, NONE, 0, false)) {
         err = b.err;
         return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
+    }
+    for (const std::vector<uint32_t>& objs : b.inst_chains) {
+        Ent c;
+        std::memset(&c, 0, sizeof(c));
+        for (size_t l = 0; l < objs.size(); l++) {
+            const rtx_object_t& o = d.objects[objs[l]];
+            c.w[4 * l] = o.kind == RTX_OBJ_TRANSLATE ? 1u : 2u;
+            for (int a = 0; a < 3; a++) c.w[4 * l + 1 + a] = fbits(o.f[a]);
+        }
+        fast.chains.push_back(c);
     }
     coord_range = b.coord_range;
     if (strict.ents.size() >= (1u << 26) || fast.ents.size() >= (1u << 26)) { err = "scene too large for 32-bit entry offsets"; return RTX_ERR_INVALID; }

@@ -607,11 +607,11 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
         uint4 ea, eb;
         reader.load(off, ea, eb);
         if (eb.w == ENT_END) break;
-        if (eb.w != ENT_BOX && (eb.w & 15u) >= ENT_XF_PUSH) {
+        if (eb.w != ENT_BOX && is_bracket_kind(eb.w & 15u)) {
             bracket_step<STRICT, SLAB>(reader, ea, eb, off, r, rc, wray, best, x, tmin, rng, rank);
         } else {
             const uint32_t at = off;
-            off = walk_step<STRICT, SLAB, QUICK>(S, ea, eb, off, r, rc, x.tmin, best, rank);
+            off = walk_step<STRICT, SLAB, QUICK>(S, reader, ea, eb, off, r, rc, x.tmin, best, rank);
             if (best.ent == at) x.best_xf = x.cur_xf;
         }
     }
@@ -1328,18 +1328,27 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
                     } else if (at_prim(st)) {  // neither box (0) nor done / idle
                         uint4 ea, eb;
                         RTX_LOAD_ENTRY(off, ea, eb);
-                        const uint32_t kind = eb.w & 15u;
                         const float lane_tmin = XF ? wx.tmin : tmin;
-                        if (XF && kind >= ENT_XF_PUSH) {
+                        if (XF && is_bracket_kind(eb.w & 15u)) {
                             // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
                             bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
                         } else {
+                            // A primitive of an instance placed in this frame's tree is tested in its own frame.  Such entries
+                            // stand outside transform brackets, where the lane's ray IS the caller's ray: the ray is moved in
+                            // place and put back from that copy afterwards.
+                            const bool inst = XF && !STRICT && (eb.w & ENT_INST) != 0u;
+                            if (inst) inst_enter(reader, ea, eb, ray, rc.a);
+                            const uint32_t kind = eb.w & 15u;
                             if (kind == ENT_SPHERE) {
                                 sphere_test<STRICT, 5, !STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);  // (fast walk: roots through the hardware square root / reciprocal)
                             } else {
                                 const uint32_t pi = eb.w >> 4;
                                 const bool tri = kind == ENT_TRI;
                                 planar_test<STRICT, !STRICT>(planar_recs, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                            }
+                            if (inst) {
+                                ray = wray;
+                                rc.a = dot3(ray.dx, ray.dy, ray.dz, ray.dx, ray.dy, ray.dz);
                             }
                             if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
                             off += ENT_BYTES;
@@ -1430,7 +1439,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
                             RTX_LOAD_ENTRY(best.ent, ha, hb);
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
                             if (XF) {
-                                h = want_uv ? make_hit_x<true, false>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false>(S, reader, ray, best, wx.best_xf);
+                                h = want_uv ? make_hit_x<true, false, !STRICT>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false, !STRICT>(S, reader, ray, best, wx.best_xf);
                             } else {
                                 h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
                             }

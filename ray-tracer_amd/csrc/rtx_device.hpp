@@ -11,6 +11,8 @@
 namespace rtxd {
 
 enum : uint32_t { ENT_BOX = 0, ENT_SPHERE = 1, ENT_QUAD = 2, ENT_TRI = 3, ENT_XF_PUSH = 4, ENT_XF_POP = 5, ENT_MED_BEGIN = 6, ENT_MED_END = 7 };
+constexpr uint32_t ENT_INST = 8;  // | ENT_SPHERE / ENT_QUAD / ENT_TRI: primitive of an instance placed in the enclosing frame's tree (accel.hpp)
+__device__ __forceinline__ bool is_bracket_kind(uint32_t kind) { return (kind & 12u) == 4u; }  // kind = word 7 & 15 of a non-box entry
 constexpr uint32_t XF_NONE = 0xFFFFFFFFu;
 // Word 7 of the entry a lane stands at is also that lane's walk state (see accel.hpp): 0 = box, ENT_END = walk
 // complete, anything else = primitive.  ST_IDLE marks a lane without a path.
@@ -329,23 +331,6 @@ template <bool STRICT, bool QUICK = false>
 __device__ __forceinline__ void planar_test(const float4* __restrict__ planar, uint32_t pidx, bool is_tri, const Ray& r, float tmin, Best& best,
                                             uint32_t idx, const uint32_t* __restrict__ rank) {
     planar_test_ld<STRICT, 5, QUICK>([&](int k) { return planar[5 * pidx + k]; }, is_tri, r, tmin, best, idx, rank);
-}
-
-// One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
-// QUICK: the primitive tests as the render kernels' fast walk evaluates them (hardware square root / reciprocal).
-template <bool STRICT, int SLAB, bool QUICK = false>
-__device__ __forceinline__ uint32_t walk_step(const DevScene& S, const uint4& ea, const uint4& eb, uint32_t off, const Ray& r, const RayConst& rc,
-                                              float tmin, Best& best, const uint32_t* __restrict__ rank) {
-    if (eb.w == ENT_BOX) return slab_hit<SLAB>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
-    const uint32_t kind = eb.w & 15u;
-    if (kind == ENT_SPHERE) {
-        sphere_test<STRICT, 5, QUICK>(ea, eb, r, rc, tmin, best, off, rank);
-    } else {
-        const uint32_t pi = eb.w >> 4;
-        const bool tri = kind == ENT_TRI;
-        planar_test<STRICT, QUICK>(S.planar, tri ? pi + S.n_quads : pi, tri, r, tmin, best, off, rank);
-    }
-    return off + ENT_BYTES;
 }
 
 // ---------------------------------------------------------------------------------------------- hit record
@@ -768,6 +753,42 @@ __device__ inline Ray xf_chain_ray(const READER& ents, uint32_t xf, const Ray& w
     return r;
 }
 
+// An ENT_INST entry: moves the ray from the frame the walk is in (the caller's: such entries exist only outside transform
+// brackets) into the primitive's own frame through the entry's chain record -- Translate::hit (mesh.rs:332), RotateY::hit
+// (mesh.rs:365-372), outermost first, the very operations the bracket entries of the instance would have applied -- and
+// turns the entry into the plain one of its primitive.  a = direction.length_squared() in that frame (mesh.rs:116).
+template <class READER>
+__device__ __forceinline__ void inst_enter(const READER& ents, uint4& ea, uint4& eb, Ray& r, float& a) {
+    const bool sph = (eb.w & 3u) == ENT_SPHERE;
+    uint4 c0, c1;
+    ents.load(sph ? ea.w : ea.y, c0, c1);
+    xf_apply(c0, r);
+    if (c1.x != 0u) xf_apply(c1, r);
+    a = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+    if (sph) ea.w = 0u;  // (the word held the chain; a sphere placed this way is at rest)
+    eb.w &= ~ENT_INST;
+}
+
+// One step of the walk for the entry (ea, eb) at byte offset off; returns the next offset.
+// QUICK: the primitive tests as the render kernels' fast walk evaluates them (hardware square root / reciprocal).
+template <bool STRICT, int SLAB, bool QUICK = false, class READER>
+__device__ __forceinline__ uint32_t walk_step(const DevScene& S, const READER& ents, uint4 ea, uint4 eb, uint32_t off, const Ray& r, const RayConst& rc,
+                                              float tmin, Best& best, const uint32_t* __restrict__ rank) {
+    if (eb.w == ENT_BOX) return slab_hit<SLAB>(ea, eb, r, rc, tmin, best.t) ? off + ENT_BYTES : eb.z;
+    Ray tr = r;
+    RayConst trc = rc;
+    if (!STRICT && (eb.w & ENT_INST) != 0u) inst_enter(ents, ea, eb, tr, trc.a);
+    const uint32_t kind = eb.w & 15u;
+    if (kind == ENT_SPHERE) {
+        sphere_test<STRICT, 5, QUICK>(ea, eb, tr, trc, tmin, best, off, rank);
+    } else {
+        const uint32_t pi = eb.w >> 4;
+        const bool tri = kind == ENT_TRI;
+        planar_test<STRICT, QUICK>(S.planar, tri ? pi + S.n_quads : pi, tri, tr, tmin, best, off, rank);
+    }
+    return off + ENT_BYTES;
+}
+
 // One walk step at a bracket entry (ea, eb) at byte offset off.  `ray` is the ray in the current frame, `wray` the
 // caller's ray; `main_tmin` the start of the caller's interval; the caller's interval end is the running best.
 template <bool STRICT, int SLAB, class READER>
@@ -843,10 +864,35 @@ __device__ inline void bracket_step(const READER& ents, const uint4& ea, const u
 // frame, then carry point and normal out through the enclosing transforms as the reference does -- Translate adds its
 // offset to the point (mesh.rs:334); RotateY re-applies its FORWARD rotation and reads the already overwritten x
 // (mesh.rs:378-382).
-template <bool WANT_UV, bool EXACT, class READER>
+template <bool WANT_UV, bool EXACT, bool INST = true, class READER>
 __device__ inline HitRec make_hit_x(const DevScene& S, const READER& ents, const Ray& wray, const Best& best, uint32_t best_xf) {
     uint4 ha, hb;
     ents.load(best.ent, ha, hb);
+    auto carry_out = [](const uint4& a, HitRec& h) {  // one level, as its hit() returns (mesh.rs:334, :378-382)
+        if (a.x == 1u) {
+            h.px += as_f(a.y);
+            h.py += as_f(a.z);
+            h.pz += as_f(a.w);
+        } else {
+            const float s = as_f(a.y), c = as_f(a.z);
+            h.px = c * h.px - s * h.pz;
+            h.pz = s * h.px + c * h.pz;
+            h.nx = c * h.nx - s * h.nz;
+            h.nz = s * h.nx + c * h.nz;
+        }
+    };
+    if (INST && (hb.w & 15u) >= ENT_INST) {  // primitive of an instance placed in the caller's frame: its chain record says how it got there
+        const uint32_t chain = (hb.w & 3u) == ENT_SPHERE ? ha.w : ha.y;
+        Ray lr = wray;
+        float a_unused;
+        inst_enter(ents, ha, hb, lr, a_unused);
+        HitRec h = make_hit<WANT_UV, EXACT>(S, ha, hb, lr, best.t);
+        uint4 c0, c1;
+        ents.load(chain, c0, c1);
+        if (c1.x != 0u) carry_out(c1, h);
+        carry_out(c0, h);
+        return h;
+    }
     const Ray lr = xf_chain_ray(ents, best_xf, wray);
     HitRec h;
     if ((hb.w & 15u) == ENT_MED_END) {  // mesh.rs:667-674
@@ -869,17 +915,7 @@ __device__ inline HitRec make_hit_x(const DevScene& S, const READER& ents, const
     for (int level = 0; level < XF_MAX_DEPTH && xf != XF_NONE; level++) {  // innermost first, as the calls return
         uint4 a, b;
         ents.load(xf, a, b);
-        if (a.x == 1u) {
-            h.px += as_f(a.y);
-            h.py += as_f(a.z);
-            h.pz += as_f(a.w);
-        } else {
-            const float s = as_f(a.y), c = as_f(a.z);
-            h.px = c * h.px - s * h.pz;
-            h.pz = s * h.px + c * h.pz;
-            h.nx = c * h.nx - s * h.nz;
-            h.nz = s * h.nx + c * h.nz;
-        }
+        carry_out(a, h);
         xf = b.x;
     }
     return h;
