@@ -61,7 +61,8 @@ struct Threaded {
     std::vector<uint32_t> rank;  // per entry: tie-break rank of a primitive / medium entry (first position in the strict order)
     std::vector<uint32_t> mat;   // per entry: material of a primitive / medium-end entry (what a hit there is shaded with), else NONE
     uint32_t n_boxes = 0, n_prims = 0;
-    bool has_brackets = false;   // contains transform or medium entries
+    bool has_brackets = false;   // contains transform or medium entries (or ENT_INST primitives)
+    bool has_frames = false;     // contains transform-enter / leave entries: a walk changes frames
     std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
     std::vector<Ent> chains;     // fast only: chain records of the ENT_INST entries (appended behind the terminator by finalize)
 };
@@ -244,6 +245,7 @@ class Builder {
             out.n_prims++;
         } else {
             if (xf_depth >= MAX_XF_DEPTH) return fail("Translate / RotateY nested deeper than 64 levels", true);
+            out.has_frames = true;
             a.w[0] = o.kind == RTX_OBJ_TRANSLATE ? 1u : 2u;
             a.w[1] = fbits(o.f[0]);
             a.w[2] = fbits(o.f[1]);
@@ -614,6 +616,7 @@ class Reorder {
         dst.n_boxes = src.n_boxes;
         dst.n_prims = src.n_prims;
         dst.has_brackets = src.has_brackets;
+        dst.has_frames = src.has_frames;
         dst.chains = src.chains;
         dst.inner.clear();
         for (uint32_t j = 0; j < n;) j = place(j, view);
@@ -1121,6 +1124,18 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     if (!b.emit_fast_subtree(fast, d.root, NONE, 0, false)) {
         err = b.err;
         return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
+    }
+    // Instances are placed all or none: an array that still needs transform brackets for some instance (nested deeper
+    // than the chain record holds, over a moving sphere or a medium) is walked by the variants that change frames, and
+    // those are kept free of the placed-primitive path.
+    if (b.place_instances && fast.has_frames && !b.inst_chains.empty()) {
+        b.place_instances = false;
+        b.inst_chains.clear();
+        fast = Threaded();
+        if (!b.emit_fast_subtree(fast, d.root, NONE, 0, false)) {
+            err = b.err;
+            return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
+        }
     }
     for (const std::vector<uint32_t>& objs : b.inst_chains) {
         Ent c;

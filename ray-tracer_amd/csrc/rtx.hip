@@ -128,6 +128,8 @@ struct rtx_scene {
     uint32_t n_images = 0;
     bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
     bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
+    bool fast_has_frames = false;  // ... and its fast array still holds transform-enter / leave entries (instances whose
+                                   // primitives could not be placed in the enclosing frame's tree)
     // the fast array in entry-index form: re-ordered for a viewpoint when a render asks for it
     std::vector<uint4> mat_recs;  // 2 per material: the shading record a hit entry gets (see DevScene::shade)
     rtx_accel::Threaded fast_indexed;
@@ -402,6 +404,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     int rc = rtx_accel::build(*d, strict, fast, s->fast_indexed, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
     if (strict.has_brackets) s->has_brackets = true;  // transforms / media need the bracket-aware kernel variant
+    s->fast_has_frames = fast.has_frames;
 
     HIP_TRY(hipGetDevice(&dc->device));
     hipDeviceProp_t prop;
@@ -847,6 +850,9 @@ struct RenderParams {
 #ifndef RTX_WIDE_WAVES
 #define RTX_WIDE_WAVES 4  // waves per SIMD the wide variants leave registers for
 #endif
+#ifndef RTX_FRAMELESS_WAVES
+#define RTX_FRAMELESS_WAVES 6  // waves per SIMD the frame-less bracket variants leave registers for (80: three spilled, +6 % over 5)
+#endif
 constexpr int TILE = 8;            // 8x8 pixels = one pixel per lane of a wave
 constexpr int MAX_WAVES_PER_BLOCK = 16;  // all waves of a block share one LDS copy of the entries; the launch picks 4, 8, 12 or 16
 constexpr int BLOCK_THREADS = 64 * MAX_WAVES_PER_BLOCK;
@@ -869,13 +875,17 @@ extern __shared__ uint4 smem[];
 // five-slot records, a per-lane stack of pending child groups in LDS.  The box stage becomes the node stage: one step
 // tests the four children of the lane's node, hands the primitives of the leaves it hit to the primitive stage and
 // descends into the nearest child node.
-template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false, bool WIDE = false>
+// NOFRAMES (with XF, fast walk): the array has media brackets and / or instance primitives placed in the caller's frame but
+// no transform-enter / leave entries, so a walk never leaves the caller's frame: no second copy of the ray, no frame ids.
+template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false, bool WIDE = false, bool NOFRAMES = false>
 // Registers per variant, through the waves per SIMD the compiler must leave room for: the lean variants 64 (8 waves), the
 // bracket variants 96 (5 waves: +10 % over 4 on the Cornell scenes, three spilled registers; at 6 they spill 47 and lose
 // 20 %), the texture variants end up at 95 on their own.
-__global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WIDE ? RTX_WIDE_WAVES : 8))) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAMELESS_WAVES : 5)) : (TEX ? 4 : (WIDE ? RTX_WIDE_WAVES : 8))) void render_kernel(RenderParams P) {
     static_assert(!PK || (!STRICT && !XF), "the packed array exists for the fast walk of bracket-free scenes only");
     static_assert(!WIDE || (PK && !ENTS_IN_LDS), "the wide array is walked from HBM in place of the packed one");
+    static_assert(!NOFRAMES || (XF && !STRICT), "only the fast array of a scene with brackets can be free of frames");
+    constexpr bool FRAMES = XF && !NOFRAMES;
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
     constexpr bool SCALED = PK && ENTS_IN_LDS;  // the walk runs in scaled ray parameters (pk_slab_hit_scaled); best.t is scaled too
@@ -1039,7 +1049,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
         best.t = __builtin_inff();       \
         best.ent = NO_HIT;               \
         if (XF) {                        \
-            wray = ray;                  \
+            if (FRAMES) wray = ray;      \
             walkx_init(wx, tmin);         \
         }                                \
         rays_traced++;                   \
@@ -1329,28 +1339,35 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
                         uint4 ea, eb;
                         RTX_LOAD_ENTRY(off, ea, eb);
                         const float lane_tmin = XF ? wx.tmin : tmin;
-                        if (XF && is_bracket_kind(eb.w & 15u)) {
+                        const uint32_t kind15 = eb.w & 15u;
+                        if (XF && (NOFRAMES ? is_bracket_kind(kind15) : kind15 >= ENT_XF_PUSH)) {
                             // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
-                            bracket_step<STRICT, SLAB>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
+                            if constexpr (FRAMES)
+                                bracket_step<STRICT, SLAB, true>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
+                            else
+                                bracket_step<STRICT, SLAB, false>(reader, ea, eb, off, ray, rc, ray, best, wx, tmin, rng, rank);
                         } else {
-                            // A primitive of an instance placed in this frame's tree is tested in its own frame.  Such entries
-                            // stand outside transform brackets, where the lane's ray IS the caller's ray: the ray is moved in
-                            // place and put back from that copy afterwards.
-                            const bool inst = XF && !STRICT && (eb.w & ENT_INST) != 0u;
-                            if (inst) inst_enter(reader, ea, eb, ray, rc.a);
-                            const uint32_t kind = eb.w & 15u;
-                            if (kind == ENT_SPHERE) {
-                                sphere_test<STRICT, 5, !STRICT>(ea, eb, ray, rc, lane_tmin, best, off, rank);  // (fast walk: roots through the hardware square root / reciprocal)
+                            // A primitive of an instance placed in this frame's tree (frame-less arrays only: the host places
+                            // either every instance of a scene or none) is tested in its own frame, with a moved copy of the ray.
+                            const uint32_t kind = NOFRAMES ? kind15 & 3u : kind15;  // (not a bracket: sphere, quad or triangle, placed or not)
+                            auto test = [&](const Ray& r_, const RayConst& rc_) {
+                                if (kind == ENT_SPHERE) {
+                                    sphere_test<STRICT, 5, !STRICT>(ea, eb, r_, rc_, lane_tmin, best, off, rank);  // (fast walk: roots through the hardware square root / reciprocal)
+                                } else {
+                                    const uint32_t pi = eb.w >> 4;
+                                    const bool tri = kind == ENT_TRI;
+                                    planar_test<STRICT, !STRICT>(planar_recs, tri ? pi + S.n_quads : pi, tri, r_, lane_tmin, best, off, rank);
+                                }
+                            };
+                            if (NOFRAMES) {
+                                Ray tr = ray;
+                                RayConst trc = rc;
+                                if ((eb.w & ENT_INST) != 0u) inst_enter(reader, ea, eb, tr, trc.a);
+                                test(tr, trc);
                             } else {
-                                const uint32_t pi = eb.w >> 4;
-                                const bool tri = kind == ENT_TRI;
-                                planar_test<STRICT, !STRICT>(planar_recs, tri ? pi + S.n_quads : pi, tri, ray, lane_tmin, best, off, rank);
+                                test(ray, rc);
                             }
-                            if (inst) {
-                                ray = wray;
-                                rc.a = dot3(ray.dx, ray.dy, ray.dz, ray.dx, ray.dy, ray.dz);
-                            }
-                            if (XF && best.ent == off) wx.best_xf = wx.cur_xf;
+                            if (FRAMES && best.ent == off) wx.best_xf = wx.cur_xf;
                             off += ENT_BYTES;
                         }
                         RTX_LOAD_STATE(off, st);
@@ -1439,7 +1456,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : 5) : (TEX ? 4 : (WID
                             RTX_LOAD_ENTRY(best.ent, ha, hb);
                             const bool want_uv = TEX && (s0.x & 512u) != 0u;
                             if (XF) {
-                                h = want_uv ? make_hit_x<true, false, !STRICT>(S, reader, ray, best, wx.best_xf) : make_hit_x<false, false, !STRICT>(S, reader, ray, best, wx.best_xf);
+                                const uint32_t hit_xf = FRAMES ? wx.best_xf : XF_NONE;
+                                h = want_uv ? make_hit_x<true, false, NOFRAMES>(S, reader, ray, best, hit_xf) : make_hit_x<false, false, NOFRAMES>(S, reader, ray, best, hit_xf);
                             } else {
                                 h = want_uv ? make_hit<true, false>(S, ha, hb, ray, best.t) : make_hit<false, false>(S, ha, hb, ray, best.t);
                             }
@@ -1836,8 +1854,13 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     static void (*const wide_kernels[2])(RenderParams) = {render_kernel<false, false, false, false, true, true>, render_kernel<false, false, false, true, true, true>};
     P.xcd_parts = K.xcd_items == 0u ? 0u : (P.tile_world == 1u ? 1u : 2u);
     if (wide) P.sched_k = K.sched_k_wide;  // (a wide step serves nodes and primitives alike: it pays to leave it for other stages sooner)
+    static void (*const frameless_kernels[4])(RenderParams) = {
+        render_kernel<false, false, true, false, false, false, true>, render_kernel<false, false, true, true, false, false, true>,
+        render_kernel<false, true, true, false, false, false, true>,  render_kernel<false, true, true, true, false, false, true>};
+    const bool frameless = M == RTX_TRAVERSAL_FAST && scene->has_brackets && !scene->fast_has_frames;
     void (*kern)(RenderParams) = wide ? wide_kernels[scene->has_tex ? 1 : 0]
                                  : pk ? packed_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
+                                 : frameless ? frameless_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
                                     : kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
 
     // noise textures read their tables 336 times per value: table set 0 goes to LDS (6 KB per block)

@@ -791,16 +791,17 @@ __device__ __forceinline__ uint32_t walk_step(const DevScene& S, const READER& e
 
 // One walk step at a bracket entry (ea, eb) at byte offset off.  `ray` is the ray in the current frame, `wray` the
 // caller's ray; `main_tmin` the start of the caller's interval; the caller's interval end is the running best.
-template <bool STRICT, int SLAB, class READER>
+// FRAMES = false: the array holds no transform-enter / leave entries (media only); wray is not read.
+template <bool STRICT, int SLAB, bool FRAMES = true, class READER>
 __device__ inline void bracket_step(const READER& ents, const uint4& ea, const uint4& eb, uint32_t& off, Ray& ray, RayConst& rc, const Ray& wray,
                                     Best& best, WalkX& x, float main_tmin, Rng& rng, const uint32_t* __restrict__ rank) {
     const uint32_t kind = eb.w & 15u;
-    if (kind == ENT_XF_PUSH) {
+    if (FRAMES && kind == ENT_XF_PUSH) {
         x.cur_xf = off;
         xf_apply(ea, ray);
         rc = ray_const<SLAB>(ray);
         off += ENT_BYTES;
-    } else if (kind == ENT_XF_POP) {
+    } else if (FRAMES && kind == ENT_XF_POP) {
         x.cur_xf = eb.x;
         ray = xf_chain_ray(ents, x.cur_xf, wray);
         rc = ray_const<SLAB>(ray);

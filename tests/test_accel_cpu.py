@@ -78,8 +78,25 @@ def walk(ents, rank, sa, ray, strict, tmin=F(0.001)):
             off = off + 32 if slab(fl[i, :6], o, d, tmin, best_t, strict) else int(ents[i, 6])
             continue
         kind, index = word & 15, word >> 4
+        if kind & 8:
+            # primitive of a Translate / RotateY instance placed in this frame's tree: the ray goes into the primitive's own
+            # frame through the entry's chain record (mesh.rs:332, :365-372), outermost level first
+            saved = (o, d, a)
+            rec = int(ents[i, 3 if (kind & 3) == 1 else 1]) // 32
+            for level in range(2):
+                what, p = int(ents[rec, 4 * level]), fl[rec, 4 * level + 1:4 * level + 4]
+                if what == 1:
+                    o = [o[k] - p[k] for k in range(3)]
+                elif what == 2:
+                    sn, cs = p[0], p[1]
+                    o = [cs * o[0] - sn * o[2], o[1], sn * o[0] + cs * o[2]]
+                    d = [cs * d[0] - sn * d[2], d[1], sn * d[0] + cs * d[2]]
+            a = dot3(d[0], d[1], d[2], d[0], d[1], d[2])
+            kind &= 3
+        else:
+            saved = None
         if kind == 1:
-            c = [fl[i, k] + fl[i, 3 + k] * time for k in range(3)]
+            c = [fl[i, k] + (fl[i, 3 + k] * time if saved is None else F(0)) for k in range(3)]  # (a placed sphere is at rest)
             oc = [c[k] - o[k] for k in range(3)]
             h = dot3(d[0], d[1], d[2], oc[0], oc[1], oc[2])
             cc = dot3(oc[0], oc[1], oc[2], oc[0], oc[1], oc[2]) - fl[i, 6] * fl[i, 6]
@@ -107,11 +124,13 @@ def walk(ents, rank, sa, ray, strict, tmin=F(0.001)):
                         best_t, best_ent = t, i
         else:
             raise AssertionError(f"entry kind {kind} is not interpreted here")
+        if saved is not None:
+            o, d, a = saved
         off += 32
     if best_ent is None:
         return MISS, INF, steps
     word = int(ents[best_ent, 7])
-    pid = sa.sph_id[word >> 4] if (word & 15) == 1 else sa.quad_id[word >> 4]
+    pid = sa.sph_id[word >> 4] if (word & 3) == 1 else sa.quad_id[word >> 4]
     return int(pid), best_t, steps
 
 
@@ -376,6 +395,86 @@ def test_threaded_arrays_walk_to_the_oracle_hits(render, oracle, scenes, name, s
         # the point of the fast tree and of the camera ordering: far fewer entries visited per ray
         assert steps["fast"] < 0.5 * steps["strict"]
         assert steps["fast ordered for the camera"] < steps["fast"]
+
+
+def test_instances_are_placed_in_the_enclosing_tree(render, oracle, scenes):
+    """cornell-box: the two Translate(RotateY(Cube)) instances leave no transform brackets in the fast array -- their
+    twelve quads stand in the scene's own tree as instance primitives with a chain record behind the terminator -- and
+    the walk through them reaches the oracle's hits with bit-identical distances.  A scene with an instance that cannot
+    be placed (a chain deeper than a record holds) keeps brackets for all of them."""
+    cfg, bvh = scenes.make("cornell-box", seed=0, width=48, height=48)
+    hs = render.Scene(bvh, upload=False)
+    sa = SceneArrays(hs.desc)
+    rays = sample_rays(oracle, cfg, bvh, 150, 120, 5)
+    want = oracle.OracleMesh(bvh).trace(rays)
+    for view in (None, np.asarray(cfg.lookfrom, dtype=F)):
+        ents, rank = hs.traversal_dump(render.TRAVERSAL_FAST, view=view)
+        end = int(np.nonzero(ents[:, 7] == ENT_END)[0][0])
+        kinds = ents[:end, 7] & 15
+        boxes = ents[:end, 7] == 0
+        assert not np.any((kinds[~boxes] >= 4) & (kinds[~boxes] < 8)), "transform brackets left in the array"
+        placed = ~boxes & ((kinds & 8) != 0)
+        assert np.count_nonzero(placed) == 12 and np.count_nonzero(~boxes) == 18
+        chains = np.unique(ents[:end][placed][:, 1])
+        assert len(ents) - end - 1 == len(chains) == 2 and np.all(chains > end * 32) and np.all(chains % 32 == 0)
+        rec = ents[chains[0] // 32]
+        assert rec[0] == 1 and rec[4] == 2  # Translate outside, RotateY inside
+        with np.errstate(all="ignore"):
+            for r, w in zip(rays, want):
+                pid, t, _ = walk(ents, rank, sa, r, False)
+                assert pid == int(w["prim_id"])
+                if pid != MISS:
+                    assert t == w["t"]
+    # the strict array keeps the reference's structure
+    strict, _ = hs.traversal_dump(render.TRAVERSAL_STRICT)
+    assert np.count_nonzero((strict[:, 7] != 0) & ((strict[:, 7] & 15) == 4)) == 4
+    os.environ["RTX_PLACE_INSTANCES"] = "0"
+    try:
+        ents, _ = render.Scene(bvh, upload=False).traversal_dump(render.TRAVERSAL_FAST)
+    finally:
+        del os.environ["RTX_PLACE_INSTANCES"]
+    assert np.count_nonzero((ents[:, 7] != 0) & ((ents[:, 7] & 15) == 4)) == 4 and not np.any((ents[:, 7] != 0) & (ents[:, 7] != ENT_END) & ((ents[:, 7] & 8) != 0))
+
+
+def _instance_world(scene, deep):
+    """A ground sphere, a cube one level deep, a sphere two levels deep and, if `deep`, a cube three levels deep."""
+    white = scene.Lambertian.rgb(0.73, 0.73, 0.73)
+    w = scene.World()
+    w.push(scene.Sphere.stationary((0.0, -1000.0, 0.0), 1000.0, scene.Lambertian.rgb(0.5, 0.6, 0.5)))
+    w.push(scene.RotateY(scene.Cube((0, 0, 0), (1.0, 1.4, 1.0), white), 25.0))
+    w.push(scene.Translate(scene.RotateY(scene.Sphere.stationary((0.0, 0.5, 0.0), 0.5, white), 33.0), (-2.0, 0.0, 1.0)))
+    if deep:
+        w.push(scene.Translate(scene.RotateY(scene.Translate(scene.Cube((0, 0, 0), (0.8, 0.8, 0.8), white), (0.2, 0.0, 0.1)), -40.0), (2.0, 0.0, -1.0)))
+    cfg = scene.CameraConfig(width=40, height=30, samples_per_pixel=1, max_depth=5, vfov=35.0, lookfrom=(6.0, 3.0, 7.0), lookat=(0.0, 0.7, 0.0),
+                             vup=(0, 1, 0))
+    return cfg, scene.Bvh(w)
+
+
+@pytest.mark.parametrize("deep", [False, True])
+def test_instances_are_placed_all_or_none(render, oracle, scene, deep):
+    """One- and two-level instances over primitives at rest are placed (chain records of one and two levels); an instance
+    nested deeper than a record holds keeps its brackets, and then every instance of the scene does."""
+    cfg, bvh = _instance_world(scene, deep)
+    hs = render.Scene(bvh, upload=False)
+    ents, rank = hs.traversal_dump(render.TRAVERSAL_FAST, view=np.asarray(cfg.lookfrom, dtype=F))
+    end = int(np.nonzero(ents[:, 7] == ENT_END)[0][0])
+    prim = ents[:end][ents[:end, 7] != 0]
+    pushes = np.count_nonzero((prim[:, 7] & 15) == 4)
+    placed = np.count_nonzero((prim[:, 7] & 8) != 0)
+    if deep:
+        assert pushes == 6 and placed == 0 and len(ents) == end + 1
+        return
+    assert pushes == 0 and placed == 7 and len(ents) == end + 3
+    sa = SceneArrays(hs.desc)
+    rays = sample_rays(oracle, cfg, bvh, 200, 150, 11)
+    want = oracle.OracleMesh(bvh).trace(rays)
+    assert len(set(want["prim_id"].tolist())) >= 5
+    with np.errstate(all="ignore"):
+        for r, w in zip(rays, want):
+            pid, t, _ = walk(ents, rank, sa, r, False)
+            assert pid == int(w["prim_id"])
+            if pid != MISS:
+                assert t == w["t"]
 
 
 def test_traversal_dump_structure(render, scenes):

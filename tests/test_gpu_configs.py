@@ -328,3 +328,45 @@ def test_deeply_nested_transforms_match_oracle(render, oracle, scene, capi):
     _, acc = render.Camera(cfg).render(gs, seed=5, traversal=render.TRAVERSAL_STRICT, want_accum=True)
     rel = np.abs(acc - ref) / (np.abs(ref) + 1e-2 * cfg.samples_per_pixel)
     assert np.median(rel) < 1e-3 and np.mean(rel < 2e-2) > 0.95
+
+
+def _placeable_instances_scene(scene):
+    """Instances one and two levels deep over primitives at rest (a cube, a sphere, a list of two quads): the fast array
+    holds their primitives in the scene's own tree instead of transform brackets."""
+    white = scene.Lambertian.rgb(0.73, 0.73, 0.73)
+    w = scene.World()
+    w.push(scene.Sphere.stationary((0.0, -1000.0, 0.0), 1000.0, scene.Lambertian.rgb(0.5, 0.6, 0.5)))
+    w.push(scene.RotateY(scene.Cube((0, 0, 0), (1.0, 1.4, 1.0), white), 25.0))
+    w.push(scene.Translate(scene.RotateY(scene.Sphere.stationary((0.0, 0.5, 0.0), 0.5, scene.Metal.rgb(0.8, 0.7, 0.6).with_roughness(0.05)), 33.0), (-2.0, 0.0, 1.0)))
+    w.push(scene.Translate(scene.Cube((0, 0, 0), (0.7, 0.7, 0.7), scene.Lambertian.rgb(0.7, 0.2, 0.2)), (2.0, 0.0, -1.0)))
+    w.push(scene.Sphere.stationary((2.2, 0.6, 1.4), 0.6, scene.Dielectric(1.5)))
+    cfg = scene.CameraConfig(width=160, height=120, samples_per_pixel=8, max_depth=20, vfov=35.0, lookfrom=(6.0, 3.0, 7.0),
+                             lookat=(0.0, 0.7, 0.0), vup=(0, 1, 0))
+    return cfg, scene.Bvh(w)
+
+
+def test_placed_instance_primitives_match_oracle(render, oracle, scene, capi):
+    """The walks over placed instance primitives (exact, and the render kernels' own) return the oracle's records -- ids,
+    t, normal and point bit for bit, the reference's back-rotation of RotateY included -- and a fast render of the
+    mirror stream is the oracle's frame."""
+    cfg, bvh = _placeable_instances_scene(scene)
+    om, gs = oracle.OracleMesh(bvh), render.Scene(bvh)
+    prim = oracle.OracleCamera(cfg).center_rays(0.5)
+    want = om.trace(prim)
+    assert len(set(want["prim_id"][want["prim_id"] != MISS].tolist())) >= 8
+    rays = np.concatenate([prim, _surface_rays(capi, want, 30_000, 4)])
+    want = om.trace(rays)
+    hit = want["prim_id"] != MISS
+    for mode in (render.TRAVERSAL_STRICT, render.TRAVERSAL_FAST, render.TRAVERSAL_RENDER):
+        got = gs.trace(rays, traversal=mode)
+        assert np.count_nonzero(got["prim_id"] != want["prim_id"]) <= (0 if mode == render.TRAVERSAL_STRICT else 2), mode
+        same = hit & (got["prim_id"] == want["prim_id"])
+        for f in ("t", "n", "p"):
+            if mode == render.TRAVERSAL_RENDER:
+                assert np.mean(np.all(np.atleast_2d(got[f][same].T == want[f][same].T), axis=0)) > 0.9999, (mode, f)
+            else:
+                assert np.array_equal(got[f][same], want[f][same]), (mode, f)
+    ref, _ = oracle.OracleCamera(cfg).render(om, seed=5, rng_kind=1)
+    _, acc = render.Camera(cfg).render(gs, seed=5, traversal=render.TRAVERSAL_FAST, want_accum=True)
+    rel = np.abs(acc - ref) / (np.abs(ref) + 1e-2 * cfg.samples_per_pixel)
+    assert np.median(rel) < 1e-3 and np.mean(rel < 2e-2) > 0.95
