@@ -372,7 +372,7 @@ int rtx_traversal_dump(const rtx_scene_desc_t* desc, uint32_t traversal, const f
  * for scenes without Translate / RotateY / ConstantMedium that are too large for on-chip memory (no counterpart in the
  * reference; replaces Bvh::hit's recursion, mesh.rs:607-625, like the other forms).  nodes_out: 16 words per node --
  * four 16-byte slots (origin.xyz, child_base) (scale.xyz, prim_base) (lo_x, lo_y, lo_z, leaves) (hi_x, hi_y, hi_z,
- * n_internal): a node has up to four children; byte j of lo_a / hi_a bounds child j on axis a as
+ * counts = n_internal | n_children << 8): a node has up to four children; byte j of lo_a / hi_a bounds child j on axis a as
  * [origin_a + scale_a * lo, origin_a + scale_a * hi] (an unused child: lo 255, hi 0).  Children j < n_internal are the
  * nodes child_base + j; the others are leaves whose primitives lie one after the other from slot prim_base in child
  * order: byte j of `leaves` = count << 5 | index of the leaf's first primitive record among the node's.

@@ -880,7 +880,7 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
 // per box), and the primitives of every leaf a node hands out are known at once.  Walking needs a per-lane stack (kept
 // in LDS); its depth is bounded by `levels`.
 //   node, 4 slots of 16 bytes:
-//     (origin.xyz, child_base)   (scale.xyz, prim_base)   (lo_x, lo_y, lo_z, leaves)   (hi_x, hi_y, hi_z, n_internal)
+//     (origin.xyz, child_base)   (scale.xyz, prim_base)   (lo_x, lo_y, lo_z, leaves)   (hi_x, hi_y, hi_z, n_internal | n_children << 8)
 //   origin = the low corner of the box around all children, scale = its extent / 255 (rounded up).  lo_a / hi_a hold one
 //   byte per child (child j in bits 8j .. 8j+7): the child's box on axis a is [origin_a + scale_a * lo, origin_a +
 //   scale_a * hi], rounded outward from the fast tree's (padded) box, so a quantised box always contains the box it
@@ -1063,7 +1063,7 @@ class WideBuilder {
         w[3] = child_base;
         w[7] = prim_base;
         w[11] = leaves;
-        w[15] = n_int;
+        w[15] = n_int | (n << 8);
         for (uint32_t k = 0; k < n_int; k++)
             if (!node(child_base + k, kids[k], level + 1)) return false;
         return true;

@@ -614,7 +614,12 @@ template <int J>
 __device__ __forceinline__ uint32_t wide_leaf_bits(uint32_t leaves, uint32_t& is_leaf) {  // primitives of leaf J; is_leaf: all ones for a leaf, else 0
     const uint32_t b = (leaves >> (8 * J)) & 255u;
     is_leaf = b != 0u ? 0xFFFFFFFFu : 0u;
-    return ((1u << (b >> 5)) - 1u) << (b & 31u);
+    // count << 5 | first  ->  `count` ones from bit `first`: two field extracts and v_bfm_b32 (which the compiler does
+    // not form from the shifts)
+    const uint32_t count = __builtin_amdgcn_ubfe(leaves, 8 * J + 5, 3), first = __builtin_amdgcn_ubfe(leaves, 8 * J, 5);
+    uint32_t m;
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(m) : "v"(count), "v"(first));
+    return m;
 }
 
 // s0 .. s3: the node's four slots
@@ -637,7 +642,7 @@ __device__ __forceinline__ void wide_node_step(const uint4& s0, const uint4& s1,
     const uint32_t m0 = wide_leaf_bits<0>(leaves, l0), m1 = wide_leaf_bits<1>(leaves, l1), m2 = wide_leaf_bits<2>(leaves, l2), m3 = wide_leaf_bits<3>(leaves, l3);
     tbase = s1.w;
     tmask = (k0 != 0xFFFFFFFFu ? m0 : 0u) | (k1 != 0xFFFFFFFFu ? m1 : 0u) | (k2 != 0xFFFFFFFFu ? m2 : 0u) | (k3 != 0xFFFFFFFFu ? m3 : 0u);
-    n_children = s3.w + (l0 & 1u) + (l1 & 1u) + (l2 & 1u) + (l3 & 1u);
+    n_children = s3.w >> 8;
     // child nodes that were hit, nearest first: a leaf's key becomes all ones like a miss
     k0 |= l0;
     k1 |= l1;

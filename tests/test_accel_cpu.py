@@ -287,7 +287,7 @@ def walk_wide(nodes, prims, rank, levels, ray, tmin=F(0.001)):
         assert n_nodes < 100000, "walk does not terminate"
         w = nodes[node]
         origin, scale = nf[node, 0:3].astype(np.float64), nf[node, 4:7].astype(np.float64)
-        child_base, prim_base, leaves, n_int = int(w[3]), int(w[7]), int(w[11]), int(w[15])
+        child_base, prim_base, leaves, n_int = int(w[3]), int(w[7]), int(w[11]), int(w[15]) & 255
         leaf = [(leaves >> (8 * j)) & 255 for j in range(4)]
         assert all(leaf[j] == 0 for j in range(n_int)), "a child node has no primitives of its own"
         hits = []
@@ -511,7 +511,8 @@ def test_wide_array_walks_to_the_oracle_hits(render, oracle, scenes, name, seed,
     nodes, prims, rank, levels = hs.wide_dump()
     n = len(nodes)
     assert nodes.shape[1] == 16 and prims.shape[0] == 5 * hs.n_prims and 1 <= levels <= 32
-    n_int = nodes[:, 15]
+    n_int = nodes[:, 15] & 255
+    assert np.all((nodes[:, 15] >> 8) == n_int + np.count_nonzero(np.stack([(nodes[:, 11] >> (8 * j)) & 255 for j in range(4)], axis=1), axis=1))
     leaf = np.stack([(nodes[:, 11] >> (8 * j)) & 255 for j in range(4)], axis=1)
     counts, starts = leaf >> 5, leaf & 31
     assert np.all(n_int <= 4) and np.all((nodes[:, 3] + n_int <= n) | (n_int == 0))
