@@ -65,10 +65,10 @@ if os.path.exists(stage):
 # 'scheduling and item turnover' also holds the wait for the state word read that ends a primitive step
 # triangle-mesh runs the wide walk: its "box steps" are walk steps that serve lanes at a node (four child boxes each) and lanes at a
 # primitive record alike, "tests/ray" there is lane-steps per ray (child-box tests per ray: 17.0, primitive tests per ray: 2.27 -- bench line)
-# previous round, same command (profiles/r2_stage_counters.txt): triangle-mesh box 35.0% primitive 9.7% service 6.0% scheduling 49.4%,
+# the packed binary walk, same command (profiles/r2_stage_counters.txt): triangle-mesh box 35.0% primitive 9.7% service 6.0% scheduling 49.4%,
 #   box steps 2.04e8 at 23.2 lanes/step + prim steps 2.2e7 at 31.6 lanes/step, 5.0e7 scheduler passes
 # cornell-box / cornell-smoke / final-scene: instances' primitives placed in the enclosing tree, frame-less variants at 6 waves per SIMD
-#   (with transform brackets, earlier this round: cornell-box box 11.8% primitive 52.0%, 1.06e8 primitive steps at 33.3 lanes, 1.08e8 scheduler passes;
+#   (with transform brackets, RTX_PLACE_INSTANCES=0: cornell-box box 11.8% primitive 52.0%, 1.06e8 primitive steps at 33.3 lanes, 1.08e8 scheduler passes;
 #    cornell-smoke 10.2% / 65.2%, 1.82e8 primitive steps at 28.5 lanes; final-scene 34.9% / 39.1%)
 """
     with open(os.path.join(dst, f"{tag}_stage_counters.txt"), "w") as g:
