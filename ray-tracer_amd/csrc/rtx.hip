@@ -698,6 +698,64 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
     hits[i] = out;
 }
 
+// RTX_TRAVERSAL_RENDER for arrays a render keeps in LDS (float boxes): the block copies the packed array to LDS address 0
+// as render_kernel<false, true, false, *, true> does, and every wave walks its 64 rays with that kernel's own pieces --
+// runs of box steps through pk_box_run_lds (here: until no lane of the wave stands at a box), primitive tests and hit
+// record through pk_render_prim / pk_render_hit -- reading entries from LDS by byte offset.
+extern __shared__ uint4 trace_smem[];
+__global__ __launch_bounds__(256) void trace_packed_lds_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
+                                                                rtx_hit_t* __restrict__ hits) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const u32x4 lds_u4;
+    for (uint32_t k = threadIdx.x; k < S.pk_slots; k += blockDim.x) trace_smem[k] = S.pk[k];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)trace_smem != 0u) __builtin_trap();  // byte offsets are LDS addresses
+    __syncthreads();
+    const auto slot = [](uint32_t o) {
+        const u32x4 v = *(lds_u4*)(uintptr_t)o;
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const uint32_t* __restrict__ rank = S.pk_rank;
+    Ray r{};
+    if (live) {
+        r.ox = rays[i].o[0]; r.oy = rays[i].o[1]; r.oz = rays[i].o[2];
+        r.dx = rays[i].d[0]; r.dy = rays[i].d[1]; r.dz = rays[i].d[2];
+        r.time = rays[i].time;
+    }
+    RayConst rc = ray_const<SLAB_FMA>(r);
+    scale_ray_const(rc);
+    Best best;
+    best.t = tmax * PK_T_SCALE;
+    best.ent = NO_HIT;
+    uint32_t off = 0, st = live ? slot(0u).w : ENT_END;
+    for (;;) {
+        const bool at_prim = st >= PK_PRIM && st < ENT_END;
+        if (__ballot(st < ENT_END) == 0ull) break;
+        if (__ballot(st < PK_PRIM) != 0ull) pk_box_run_lds(off, st, rc, best.t, 1u, 1u);
+        if (at_prim) {
+            const uint32_t at = off;
+            off += pk_render_prim<true>(slot(at), slot(at + PK_SLOT), [&](int k) { return slot(at + (uint32_t)k * PK_SLOT); }, at, r, rc, tmin, best, rank);
+            st = slot(off).w;
+        }
+    }
+    if (!live) return;
+    rtx_hit_t out;
+    std::memset(&out, 0, sizeof(out));
+    out.prim_id = RTX_MISS;
+    if (best.ent != NO_HIT) {
+        const uint32_t at = best.ent;
+        const HitRec h = pk_render_hit<true, true, true>(S, [&](int k) { return slot(at + (uint32_t)k * PK_SLOT); }, r, best.t);
+        out.prim_id = h.prim_id;
+        out.t = best.t * PK_T_UNSCALE;
+        out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
+        out.uv[0] = h.u; out.uv[1] = h.v;
+        out.front_face = 1;  // Hit::new stores `front_face: true` unconditionally (mesh.rs:47)
+        out.p[0] = h.px; out.p[1] = h.py; out.p[2] = h.pz;
+    }
+    hits[i] = out;
+}
+
 // The same contract over the wide form of the fast array: the node step and the primitive tests of
 // render_kernel<..., PK, WIDE>, with the stack of pending groups in private memory.
 // RENDER = false: exact roots and hit record (RTX_TRAVERSAL_FAST_FUSED); true: the render kernels' (RTX_TRAVERSAL_RENDER).
@@ -761,6 +819,8 @@ __global__ __launch_bounds__(256) void trace_wide_kernel(DevScene S, const rtx_r
     hits[i] = out;
 }
 
+static int kernel_allow_lds(const void* kern, int device, size_t lds);
+
 extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
                                 void* stream) {
     if (!scene || !opts || (n && (!rays_dev || !hits_dev))) return fail(RTX_ERR_INVALID, "null argument");
@@ -783,8 +843,12 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
     // RTX_TRAVERSAL_RENDER: the walk of the render kernel variant a fast render of this scene launches
     else if (scene->wide)  // render_kernel<false, false, false, *, true, true>: four-child nodes
         hipLaunchKernelGGL((trace_wide_kernel<true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
-    else if (scene->packed && !scene->pk_half)  // render_kernel<false, true, false, *, true>: float boxes, scaled ray parameters
-        hipLaunchKernelGGL((trace_packed_kernel<true, true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    else if (scene->packed && !scene->pk_half) {  // render_kernel<false, true, false, *, true>: float boxes in LDS, scaled ray parameters
+        const size_t lds = (size_t)S.pk_slots * 16;
+        int rc = kernel_allow_lds((const void*)trace_packed_lds_kernel, scene->primary.device, lds);
+        if (rc != RTX_OK) return rc;
+        hipLaunchKernelGGL(trace_packed_lds_kernel, grid, block, lds, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+    }
     else if (scene->packed)  // render_kernel<false, false, false, *, true>: half-precision boxes
         hipLaunchKernelGGL((trace_packed_kernel<true, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else  // render_kernel<false, *, *, *, false>: 32-byte entries (scenes with Translate / RotateY / ConstantMedium)
@@ -1271,27 +1335,36 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                     // lanes that are not at a box never read e / e1: leave their registers as they are instead of clearing them
                     uint4 e, e1;
                     asm("" : "=v"(e.x), "=v"(e.y), "=v"(e.z), "=v"(e.w), "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w));
-                    if (here) {
-                        RTX_LOAD_SLOT(off, e);
-                        if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
-                    }
                     uint32_t tests = 0;  // summed in the loop's own scalar and added to the wave's tally once per pass
-                    do {
-                        tests += nb;
-#ifdef RTX_STAGE_COUNTERS
-                        sc[0]++;
-                        sc[1] += nb;
+#if defined(RTX_STAGE_COUNTERS) || defined(RTX_BOX_LOOP_COMPILED)
+                    constexpr bool BOX_RUN = false;  // (the stage counters count steps in the loop below)
+#else
+                    constexpr bool BOX_RUN = ENTS_IN_LDS;
 #endif
+                    if (BOX_RUN) {
+                        tests = pk_box_run_lds(off, st, rc, best.t, k1, n_fixed);  // the loop below, hand-scheduled
+                    } else {
                         if (here) {
-                            const bool hit = pk_render_box<SCALED>(e, e1, rc, tmin, best.t);
-                            off = hit ? off + BOX_BYTES : (ENTS_IN_LDS ? st : st * PK_SLOT);  // float boxes carry byte links
                             RTX_LOAD_SLOT(off, e);
                             if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
-                            st = e.w;
                         }
-                        here = at_box(st);
-                        nb = (uint32_t)__popcll(__ballot(here));
-                    } while (nb * k1 >= n_fixed && nb > 0);
+                        do {
+                            tests += nb;
+#ifdef RTX_STAGE_COUNTERS
+                            sc[0]++;
+                            sc[1] += nb;
+#endif
+                            if (here) {
+                                const bool hit = pk_render_box<SCALED>(e, e1, rc, tmin, best.t);
+                                off = hit ? off + BOX_BYTES : (ENTS_IN_LDS ? st : st * PK_SLOT);  // float boxes carry byte links
+                                RTX_LOAD_SLOT(off, e);
+                                if (ENTS_IN_LDS) RTX_LOAD_SLOT(off + PK_SLOT, e1);
+                                st = e.w;
+                            }
+                            here = at_box(st);
+                            nb = (uint32_t)__popcll(__ballot(here));
+                        } while (nb * k1 >= n_fixed && nb > 0);
+                    }
                     wave_box += tests;
                 } else {
                     uint4 ea, eb;  // (as above: only lanes at a box read them)
