@@ -732,7 +732,8 @@ __global__ __launch_bounds__(256) void trace_packed_lds_kernel(DevScene S, const
     for (;;) {
         const bool at_prim = st >= PK_PRIM && st < ENT_END;
         if (__ballot(st < ENT_END) == 0ull) break;
-        if (__ballot(st < PK_PRIM) != 0ull) pk_box_run_lds(off, st, rc, best.t, 1u, 1u);
+        const unsigned long long boxes = __ballot(st < PK_PRIM);
+        if (boxes != 0ull) pk_box_run_lds(boxes, off, st, rc, best.t, 1u, 1u);
         if (at_prim) {
             const uint32_t at = off;
             off += pk_render_prim<true>(slot(at), slot(at + PK_SLOT), [&](int k) { return slot(at + (uint32_t)k * PK_SLOT); }, at, r, rc, tmin, best, rank);
@@ -1217,12 +1218,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     RTX_CLAIM(0u);
     if (live != 0u) {
         for (;;) {
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(at_box(st)));
+            const unsigned long long box_lanes = __ballot(at_box(st));
+            const uint32_t n_box = (uint32_t)__popcll(box_lanes);
             // finished walks and free lanes: the two largest state words, one compare for both
             static_assert(ENT_END == 0xFFFFFFFEu && ST_IDLE == 0xFFFFFFFFu, "done and idle are the two largest state words");
             const uint32_t n_rest = (uint32_t)__popcll(__ballot(st >= ENT_END));
             const uint32_t n_prim = 64u - n_box - n_rest;
-            if (pool_next >= pool_total) {
+            if (__builtin_expect(pool_next >= pool_total, 0)) {
                 // write out the items no lane carries a path of: the tile's sums go into the batch's partial image (each
                 // pixel of each batch has exactly one writer)
                 const uint32_t my_item = st != ST_IDLE ? slot >> 6 : 0xFFFFFFFFu;
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             // lanes the service stage has work for: every finished walk, and as many free lanes as the pool has pairs for
             // (the free lanes are counted only when the pool is nearly empty)
             uint32_t n_serv = n_rest;
-            if (pool_left < 64u) {
+            if (__builtin_expect(pool_left < 64u, 0)) {
                 const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
                 n_serv = n_rest - n_idle + min(n_idle, pool_left);
             }
@@ -1257,7 +1259,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
 
             // run the stage with the best score: queue length weighted by a per-stage constant (eighths)
             const uint32_t sc_box = n_box * 8u, sc_prim = n_prim * P.w_prim, sc_serv = n_serv * P.w_serv;
-            if (n_box != 0u && sc_box >= sc_prim && sc_box >= sc_serv) {
+            // (some lane has work and the weights are at least 1, so the largest score is not 0: a stage without lanes never wins)
+            if (sc_box >= max(sc_prim, sc_serv)) {
                 // ---- extend, box stage: Aabb::hit for the lanes standing at a box; keep going while boxes stay the
                 //      largest queue (one ballot per step: everything that is not BOX is "the rest")
                 const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
@@ -1342,7 +1345,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                     constexpr bool BOX_RUN = ENTS_IN_LDS;
 #endif
                     if (BOX_RUN) {
-                        tests = pk_box_run_lds(off, st, rc, best.t, k1, n_fixed);  // the loop below, hand-scheduled
+                        tests = pk_box_run_lds(box_lanes, off, st, rc, best.t, k1, n_fixed);  // the loop below, hand-scheduled
                     } else {
                         if (here) {
                             RTX_LOAD_SLOT(off, e);
@@ -1386,7 +1389,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                     } while (nb * P.sched_k >= (n_fixed - nb) && nb > 0);
                 }
                 RTX_TOC(0);
-            } else if (n_prim != 0u && (sc_prim >= sc_serv || n_serv == 0u)) {
+            } else if (sc_prim >= sc_serv) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive; repeated
                 //      while primitives stay the bulk of the work (lists, leaves and instances put them in a row)
                 const uint32_t n_fixed = n_box + n_prim + n_serv;

@@ -482,16 +482,15 @@ __device__ __forceinline__ bool pk_slab_hit_scaled(const uint4& s0, const uint4&
 // this loop -- a mask saved, tested and restored around the step, the wave's condition kept as a lane mask -- spends
 // thirteen scalar instructions per step where five do: lanes that leave are simply taken out of EXEC.
 // The first two slots of the current entry live in v[56:59] (centre.xyz, state) and v[60:63] (half extent.xyz, -).
-__device__ __forceinline__ uint32_t pk_box_run_lds(uint32_t& off, uint32_t& st, const RayConst& rc, float tmax_scaled, uint32_t k1, uint32_t n_fixed) {
+// at_box: the wave's lanes whose state word says "box" (the caller has that mask from its own count), not empty.
+__device__ __forceinline__ uint32_t pk_box_run_lds(unsigned long long at_box, uint32_t& off, uint32_t& st, const RayConst& rc, float tmax_scaled, uint32_t k1,
+                                                   uint32_t n_fixed) {
     uint32_t tests, nb, tmp;
-    unsigned long long saved, joined;
+    unsigned long long saved;
     float t0, t1, t2;
     asm volatile(
         "s_mov_b64 %[saved], exec\n"
-        "v_cmp_gt_u32 vcc, %[prim], %[st]\n"
         "s_mov_b32 %[tests], 0\n"
-        "s_and_b64 %[joined], exec, vcc\n"
-        "s_cbranch_scc0 2f\n"
         "s_mov_b64 exec, %[joined]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "ds_read_b128 v[56:59], %[off]\n"
@@ -529,12 +528,11 @@ __device__ __forceinline__ uint32_t pk_box_run_lds(uint32_t& off, uint32_t& st, 
         "s_mov_b64 exec, %[joined]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "v_mov_b32 %[st], v59\n"
-        "2:\n"
         "s_mov_b64 exec, %[saved]\n"
-        : [off] "+v"(off), [st] "+v"(st), [tests] "=&s"(tests), [nb] "=&s"(nb), [tmp] "=&s"(tmp), [saved] "=&s"(saved), [joined] "=&s"(joined),
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [off] "+v"(off), [st] "+v"(st), [tests] "=&s"(tests), [nb] "=&s"(nb), [tmp] "=&s"(tmp), [saved] "=&s"(saved), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [t2] "=&v"(t2)
         : [ix] "v"(rc.ix), [iy] "v"(rc.iy), [iz] "v"(rc.iz), [nx] "v"(rc.nx), [ny] "v"(rc.ny), [nz] "v"(rc.nz), [tmax] "v"(tmax_scaled), [k1] "s"(k1),
-          [nfix] "s"(n_fixed), [prim] "s"(PK_PRIM)
+          [nfix] "s"(n_fixed), [prim] "s"(PK_PRIM), [joined] "s"(at_box)
         : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
     return tests;
 }
