@@ -1224,7 +1224,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             static_assert(ENT_END == 0xFFFFFFFEu && ST_IDLE == 0xFFFFFFFFu, "done and idle are the two largest state words");
             const uint32_t n_rest = (uint32_t)__popcll(__ballot(st >= ENT_END));
             const uint32_t n_prim = 64u - n_box - n_rest;
-            if (__builtin_expect(pool_next >= pool_total, 0)) {
+            // Fast path: the pool holds a pair for every lane, so every finished or free lane can be served and all 64
+            // lanes have or can get work.  Everything else -- the pool running low or out, items to write out and to
+            // claim -- sits behind one test of what the pool has left.
+            uint32_t n_serv = n_rest, n_fixed = 64u;
+            if (__builtin_expect(pool_total - pool_next < 64u, 0)) {  // (pool_next never passes pool_total)
+            if (pool_next >= pool_total) {
                 // write out the items no lane carries a path of: the tile's sums go into the batch's partial image (each
                 // pixel of each batch has exactly one writer)
                 const uint32_t my_item = st != ST_IDLE ? slot >> 6 : 0xFFFFFFFFu;
@@ -1244,15 +1249,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                 if (more && live != all_slots) RTX_CLAIM((uint32_t)__builtin_ctz(~live));  // free lanes move on to the next item
                 if (live == 0u) break;  // nothing left anywhere
             }
-            const uint32_t pool_left = pool_total - pool_next;  // (pool_next never passes pool_total)
+            const uint32_t pool_left = pool_total - pool_next;
             // lanes the service stage has work for: every finished walk, and as many free lanes as the pool has pairs for
-            // (the free lanes are counted only when the pool is nearly empty)
-            uint32_t n_serv = n_rest;
-            if (__builtin_expect(pool_left < 64u, 0)) {
+            if (pool_left < 64u) {
                 const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
                 n_serv = n_rest - n_idle + min(n_idle, pool_left);
             }
-            if (n_box + n_prim + n_serv == 0) continue;  // only possible while A drains a zero-depth pool
+            n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
+            if (n_fixed == 0u) continue;  // only possible while an item with a zero-depth pool drains
+            }
 #ifdef RTX_STAGE_COUNTERS
             sc[7]++;
 #endif
@@ -1263,7 +1268,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             if (sc_box >= max(sc_prim, sc_serv)) {
                 // ---- extend, box stage: Aabb::hit for the lanes standing at a box; keep going while boxes stay the
                 //      largest queue (one ballot per step: everything that is not BOX is "the rest")
-                const uint32_t n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
                 uint32_t nb = n_box;
                 RTX_TIC();
                 if (WIDE) {
@@ -1392,7 +1396,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             } else if (sc_prim >= sc_serv) {
                 // ---- extend, primitive stage: Sphere::hit / Quad::hit for the lanes standing at a primitive; repeated
                 //      while primitives stay the bulk of the work (lists, leaves and instances put them in a row)
-                const uint32_t n_fixed = n_box + n_prim + n_serv;
                 uint32_t np = n_prim;
                 RTX_TIC();
                 do {
@@ -1590,7 +1593,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                 // ---- service stage 2, ray generation: free lanes take the next (pixel, sample) pairs of the pool
                 //      (camera.rs:147-163)
                 const unsigned long long idle = __ballot(st == ST_IDLE);
-                if (idle && pool_left != 0u) {
+                if (idle && pool_next < pool_total) {
                     const uint32_t g_tx = cur_txy & 0xFFFFu, g_ty = cur_txy >> 16;
                     const uint32_t g_s0 = Q->sample_begin + cur_batch * Q->batch;
                     const uint32_t my = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
