@@ -63,6 +63,8 @@ if os.path.exists(stage):
             out.append(l)
     note = """# the stage clocks include the clock reads themselves (each waits for outstanding memory reads), so they overstate the short stages;
 # 'scheduling and item turnover' also holds the wait for the state word read that ends a primitive step
+# (a library built with -DRTX_STAGE_COUNTERS keeps the compiled box loop of the packed LDS walk, which counts its steps; the product kernel runs
+#  the hand-written pk_box_run_lds there, about a quarter cheaper per step: the box share of bouncing-spheres below is the compiled loop's)
 # triangle-mesh runs the wide walk: its "box steps" are walk steps that serve lanes at a node (four child boxes each) and lanes at a
 # primitive record alike, "tests/ray" there is lane-steps per ray (child-box tests per ray: 17.0, primitive tests per ray: 2.27 -- bench line)
 # the packed binary walk, same command (profiles/r2_stage_counters.txt): triangle-mesh box 35.0% primitive 9.7% service 6.0% scheduling 49.4%,
