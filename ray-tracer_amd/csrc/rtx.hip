@@ -733,7 +733,8 @@ __global__ __launch_bounds__(256) void trace_packed_lds_kernel(DevScene S, const
         const bool at_prim = st >= PK_PRIM && st < ENT_END;
         if (__ballot(st < ENT_END) == 0ull) break;
         const unsigned long long boxes = __ballot(st < PK_PRIM);
-        if (boxes != 0ull) pk_box_run_lds(boxes, off, st, rc, best.t, 1u, 1u);
+        uint32_t steps = 0;
+        if (boxes != 0ull) pk_box_run_lds(boxes, off, st, steps, rc, best.t, 1u);
         if (at_prim) {
             const uint32_t at = off;
             off += pk_render_prim<true>(slot(at), slot(at + PK_SLOT), [&](int k) { return slot(at + (uint32_t)k * PK_SLOT); }, at, r, rc, tmin, best, rank);
@@ -901,6 +902,7 @@ struct RenderParams {
     uint32_t sched_k;     // box stage keeps running while n_box * sched_k >= lanes queued elsewhere
     uint32_t w_prim, w_serv;  // stage weights (eighths) of the primitive and service queues against the box queue
     uint32_t w_mix;       // wide walk: see the walk stage
+    uint32_t box_run_min; // ceil(64 / (sched_k + 1)): the lanes a box run of the packed LDS walk needs to go on when all 64 have work
     uint32_t sched_kp;    // primitive stage keeps running while n_prim * sched_kp >= 8 * lanes queued elsewhere (0 = one step)
     uint32_t perlin_in_lds;  // 1: the launch reserved 6 KB of LDS per block for Perlin table set 0
     uint32_t planar_in_lds;  // quad / triangle records (80 bytes each) the launch reserved LDS for, behind the Perlin tables: all of them or 0
@@ -1004,7 +1006,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     const float tmin = 0.001f;  // Camera::ray_color's interval start (camera.rs:127)
     uint32_t rays_traced = 0;  // per lane; summed in 64 bits at the end
     uint32_t wave_box = 0, wave_prim = 0;  // wave-uniform: lanes x steps of the box / primitive stage = tests performed
-    uint32_t lane_box = 0;                 // WIDE: child boxes this lane tested (a node has two to four)
+    uint32_t lane_box = 0;                 // box tests of this lane where they are counted per lane: the wide walk (child boxes, two to four
+                                           // per node) and the box runs of the packed LDS walk
 #ifdef RTX_STAGE_COUNTERS
     unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
     unsigned long long tc[4] = {0, 0, 0, 0};              // wave clocks inside the box / primitive / service stage, and in total
@@ -1349,7 +1352,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                     constexpr bool BOX_RUN = ENTS_IN_LDS;
 #endif
                     if (BOX_RUN) {
-                        tests = pk_box_run_lds(box_lanes, off, st, rc, best.t, k1, n_fixed);  // the loop below, hand-scheduled
+                        // the loop below, hand-scheduled; it goes on while lanes x k1 >= n_fixed
+                        const uint32_t min_lanes = n_fixed == 64u ? P.box_run_min : (n_fixed + k1 - 1u) / k1;
+                        pk_box_run_lds(box_lanes, off, st, lane_box, rc, best.t, min_lanes);
                     } else {
                         if (here) {
                             RTX_LOAD_SLOT(off, e);
@@ -1645,12 +1650,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     unsigned long long wave_rays = rays_traced;
     for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
     unsigned long long wave_lane_box = lane_box;
-    if (WIDE)
+    if (WIDE || (PK && ENTS_IN_LDS))
         for (int o = 32; o > 0; o >>= 1) wave_lane_box += __shfl_down(wave_lane_box, o);
     unsigned long long* const tally = reinterpret_cast<unsigned long long*>(acc);
     if (lane == 0) {
         tally[0] = wave_rays;
-        tally[1] = WIDE ? wave_lane_box : (unsigned long long)wave_box;
+        tally[1] = wave_lane_box + (unsigned long long)wave_box;  // (the wide walk and the packed LDS walk count per lane, the others per wave)
         tally[2] = wave_prim;
     }
     __syncthreads();
@@ -1931,6 +1936,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
         render_kernel<false, false, false, false, true>, render_kernel<false, false, false, true, true>,
         render_kernel<false, true, false, false, true>,  render_kernel<false, true, false, true, true>};
     static void (*const wide_kernels[2])(RenderParams) = {render_kernel<false, false, false, false, true, true>, render_kernel<false, false, false, true, true, true>};
+    P.box_run_min = (64u + K.sched_k) / (K.sched_k + 1u);
     P.xcd_parts = K.xcd_items == 0u ? 0u : (P.tile_world == 1u ? 1u : 2u);
     if (wide) P.sched_k = K.sched_k_wide;  // (a wide step serves nodes and primitives alike: it pays to leave it for other stages sooner)
     static void (*const frameless_kernels[4])(RenderParams) = {

@@ -475,33 +475,33 @@ __device__ __forceinline__ bool pk_slab_hit_scaled(const uint4& s0, const uint4&
 // A run of box steps over the copy of the packed array (float boxes) that starts at LDS address 0, for the lanes of the
 // wave whose state word says "box": each step is pk_slab_hit_scaled, then the lane moves to the next entry (hit) or to
 // the box's miss link (its state word, a byte offset) and reads that entry's first two slots.  A lane leaves the run
-// when it arrives at an entry that is not a box; the run ends for all when the lanes left, times k1, are fewer than
-// n_fixed (k1 = n_fixed = 1: until none is left).  Returns the box tests performed (lanes x steps).
+// when it arrives at an entry that is not a box; the run ends for all when fewer than min_lanes (>= 1) are left.
+// lane_tests counts the lane's own steps (the wave's box tests are the sum over its lanes).
 // Written out instruction by instruction because of what the loop costs around the test itself: the wave is bound by
 // instruction issue, scalar instructions included (six more of them per step cost 14 %), and the compiler's form of
 // this loop -- a mask saved, tested and restored around the step, the wave's condition kept as a lane mask -- spends
-// thirteen scalar instructions per step where five do: lanes that leave are simply taken out of EXEC.
-// The first two slots of the current entry live in v[56:59] (centre.xyz, state) and v[60:63] (half extent.xyz, -).
+// thirteen scalar instructions per step where four do: lanes that leave are simply taken out of EXEC, the lanes left are
+// counted from EXEC and compared with a threshold the caller derives once per run.  The two vector instructions
+// between the compare that decides hit / miss and the select that consumes it (the step counter, the address of the
+// next entry) are the wait states that pair needs.
 // at_box: the wave's lanes whose state word says "box" (the caller has that mask from its own count), not empty.
-__device__ __forceinline__ uint32_t pk_box_run_lds(unsigned long long at_box, uint32_t& off, uint32_t& st, const RayConst& rc, float tmax_scaled, uint32_t k1,
-                                                   uint32_t n_fixed) {
-    uint32_t tests, nb, tmp;
+// The first two slots of the current entry live in v[56:59] (centre.xyz, state) and v[60:63] (half extent.xyz, -).
+__device__ __forceinline__ void pk_box_run_lds(unsigned long long at_box, uint32_t& off, uint32_t& st, uint32_t& lane_tests, const RayConst& rc,
+                                               float tmax_scaled, uint32_t min_lanes) {
+    uint32_t nb;
     unsigned long long saved;
     float t0, t1, t2;
     asm volatile(
         "s_mov_b64 %[saved], exec\n"
-        "s_mov_b32 %[tests], 0\n"
         "s_mov_b64 exec, %[joined]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "ds_read_b128 v[56:59], %[off]\n"
         "ds_read_b128 v[60:63], %[off] offset:16\n"
-        "s_bcnt1_i32_b64 %[nb], exec\n"
         "s_waitcnt lgkmcnt(1)\n"
         "1:\n"
         "v_fma_f32 %[t0], v56, %[ix], %[nx]\n"
         "v_fma_f32 %[t1], v57, %[iy], %[ny]\n"
         "v_fma_f32 %[t2], v58, %[iz], %[nz]\n"
-        "s_add_u32 %[tests], %[tests], %[nb]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "v_fma_f32 v56, -v60, |%[ix]|, %[t0]\n"
         "v_fma_f32 v57, -v61, |%[iy]|, %[t1]\n"
@@ -512,9 +512,9 @@ __device__ __forceinline__ uint32_t pk_box_run_lds(unsigned long long at_box, ui
         "v_max3_f32 v56, v56, v57, v58\n"
         "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n"
         "v_min_f32 %[t0], %[t0], %[tmax]\n"
-        "v_add_u32 %[t1], 32, %[off]\n"
         "v_cmp_nle_f32 vcc, %[t0], v56\n"
-        "s_nop 1\n"
+        "v_add_u32 %[cnt], 1, %[cnt]\n"
+        "v_add_u32 %[t1], 32, %[off]\n"
         "v_cndmask_b32 %[off], v59, %[t1], vcc\n"
         "ds_read_b128 v[56:59], %[off]\n"
         "ds_read_b128 v[60:63], %[off] offset:16\n"
@@ -522,19 +522,16 @@ __device__ __forceinline__ uint32_t pk_box_run_lds(unsigned long long at_box, ui
         "v_cmp_gt_u32 vcc, %[prim], v59\n"
         "s_and_b64 exec, exec, vcc\n"
         "s_bcnt1_i32_b64 %[nb], exec\n"
-        "s_mul_i32 %[tmp], %[nb], %[k1]\n"
-        "s_cmp_ge_u32 %[tmp], %[nfix]\n"
+        "s_cmp_ge_u32 %[nb], %[thr]\n"
         "s_cbranch_scc1 1b\n"
         "s_mov_b64 exec, %[joined]\n"
         "s_waitcnt lgkmcnt(0)\n"
         "v_mov_b32 %[st], v59\n"
         "s_mov_b64 exec, %[saved]\n"
-        : [off] "+v"(off), [st] "+v"(st), [tests] "=&s"(tests), [nb] "=&s"(nb), [tmp] "=&s"(tmp), [saved] "=&s"(saved), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [t2] "=&v"(t2)
-        : [ix] "v"(rc.ix), [iy] "v"(rc.iy), [iz] "v"(rc.iz), [nx] "v"(rc.nx), [ny] "v"(rc.ny), [nz] "v"(rc.nz), [tmax] "v"(tmax_scaled), [k1] "s"(k1),
-          [nfix] "s"(n_fixed), [prim] "s"(PK_PRIM), [joined] "s"(at_box)
+        : [off] "+v"(off), [st] "+v"(st), [cnt] "+v"(lane_tests), [nb] "=&s"(nb), [saved] "=&s"(saved), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [ix] "v"(rc.ix), [iy] "v"(rc.iy), [iz] "v"(rc.iz), [nx] "v"(rc.nx), [ny] "v"(rc.ny), [nz] "v"(rc.nz), [tmax] "v"(tmax_scaled),
+          [thr] "s"(min_lanes), [prim] "s"(PK_PRIM), [joined] "s"(at_box)
         : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-    return tests;
 }
 
 // Reads slots of the packed array through a generic pointer (trace kernel, rare paths).
