@@ -258,6 +258,36 @@ def test_render_walk_small_scenes(render, oracle, scenes, capi, name, seed, w, h
     check_render_walk(scene.trace(sec, traversal=render.TRAVERSAL_RENDER), om.trace(sec), sec, info, f"{name} secondary half={half}")
 
 
+def test_render_walk_array_near_the_lds_limit(render, oracle, scene, capi):
+    """A packed array of ~66 KB (700 spheres): still rendered from LDS, above the 48 KB a kernel gets without asking --
+    the render walk's LDS copy (trace) and the render itself both have to request it."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    w = scene.World()
+    w.push(scene.Sphere.stationary((0.0, -1000.0, 0.0), 1000.0, scene.Lambertian.rgb(0.5, 0.5, 0.5)))
+    for k in range(699):
+        c = (float(rng.uniform(-12, 12)), float(rng.uniform(0.15, 2.5)), float(rng.uniform(-12, 12)))
+        w.push(scene.Sphere.stationary(c, float(rng.uniform(0.1, 0.3)), scene.Lambertian.rgb(0.6, 0.4, 0.3)))
+    cfg = scene.CameraConfig(width=320, height=200, samples_per_pixel=1, max_depth=8, vfov=30.0, lookfrom=(13.0, 3.0, 4.0), lookat=(0.0, 0.5, 0.0),
+                             vup=(0, 1, 0))
+    bvh = scene.Bvh(w)
+    om, gs = oracle.OracleMesh(bvh), render.Scene(bvh)
+    info = PrimInfo(gs)
+    buf = torch.zeros(cfg.width * cfg.height * 3, device="cuda")
+    st = render.Stats()
+    render.Camera(cfg).render_accumulate(gs, buf.data_ptr(), 0, 1, seed=1, stream=torch.cuda.current_stream().cuda_stream, stats=st)
+    torch.cuda.synchronize()
+    assert (st.flags & 3) == 3  # packed array, walked from LDS
+    slots, _ = gs.traversal_dump(render.TRAVERSAL_FAST_FUSED)
+    assert 60 * 1024 < slots.shape[0] * 16 <= 72 * 1024
+    rays = oracle.OracleCamera(cfg).center_rays(0.5)
+    want = om.trace(rays)
+    check_render_walk(gs.trace(rays, traversal=render.TRAVERSAL_RENDER), want, rays, info, "700 spheres primary")
+    sec = _surface_rays(capi, want, 40_000, 9)
+    check_render_walk(gs.trace(sec, traversal=render.TRAVERSAL_RENDER), om.trace(sec), sec, info, "700 spheres secondary")
+
+
 @pytest.mark.parametrize("half", [False, True])
 def test_render_walk_axis_parallel_and_interval(render, oracle, scenes, capi, half, monkeypatch):
     """Rays with exactly-zero direction components (1/d infinite: the scaled, clamped box test must not cull a box that
