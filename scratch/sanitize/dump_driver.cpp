@@ -44,6 +44,28 @@ static int dump_all(const Mesh& root, const char* name, bool has_brackets) {
             }
         }
     }
+    if (!has_brackets) {  // the wide form (four-child nodes): built for any bracket-free scene when asked for
+        for (float grow : {0.0f, 1e-3f}) {
+            size_t nn = 0, ns = 0;
+            uint32_t levels = 0;
+            int rc = rtx_wide_dump(&d, grow, nullptr, 0, nullptr, nullptr, 0, &nn, &ns, &levels);
+            if (rc == RTX_ERR_UNSUPPORTED) continue;
+            if (rc != RTX_OK) {
+                std::printf("%s wide: size query failed: %s\n", name, rtx_last_error());
+                fails++;
+                continue;
+            }
+            std::vector<uint32_t> nodes(nn * 16), prims(ns * 4), wrank(ns);
+            if (rtx_wide_dump(&d, grow, nodes.data(), nn, prims.data(), wrank.data(), ns, &nn, &ns, &levels) != RTX_OK) {
+                std::printf("%s wide: dump failed: %s\n", name, rtx_last_error());
+                fails++;
+            }
+            if (nn > 1 && rtx_wide_dump(&d, grow, nodes.data(), nn - 1, prims.data(), wrank.data(), ns, &nn, &ns, &levels) == RTX_OK) {
+                std::printf("%s wide: short capacity accepted\n", name);
+                fails++;
+            }
+        }
+    }
     std::printf("%-24s %zu spheres %zu quads %zu tris %zu objects: %s\n", name, b.sph[0].size(), b.quad[0].size(), b.tri[0].size(), b.objects.size(),
                 fails ? "FAILED" : "ok");
     return fails;
@@ -105,6 +127,19 @@ int main() {
         for (int i = 0; i < 40; i++) deep = i % 2 ? MeshP(std::make_shared<Translate>(deep, Vec3(1, 0, 1))) : MeshP(std::make_shared<RotateY>(deep, 2.0f));
         w.push(deep);
         fails += dump_all(*Bvh::from(w), "instances + media", true);
+    }
+    {  // instances that can all be placed in the enclosing tree (one and two levels over primitives at rest), one inside a medium
+        World w;
+        auto white = Lambertian::rgb(.73f, .73f, .73f);
+        w.push(std::make_shared<Quad>(Vec3(0, 0, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+        MeshP box1 = std::make_shared<Cube>(Vec3(0, 0, 0), Vec3(165, 330, 165), white);
+        box1 = std::make_shared<Translate>(std::make_shared<RotateY>(box1, 15.0f), Vec3(265, 0, 295));
+        w.push(std::make_shared<ConstantMedium>(box1, 0.01f, SolidTexture::rgb(0, 0, 0)));
+        w.push(std::make_shared<RotateY>(std::make_shared<Cube>(Vec3(0, 0, 0), Vec3(100, 100, 100), white), -18.0f));
+        World cluster;
+        for (int i = 0; i < 300; i++) cluster.push(Sphere::stationary(Vec3(165 * U(rng), 165 * U(rng), 165 * U(rng)), 10, white));
+        w.push(std::make_shared<Translate>(std::make_shared<RotateY>(Bvh::from(cluster), 15.0f), Vec3(-100, 270, 395)));
+        fails += dump_all(*Bvh::from(w), "placed instances", true);
     }
     std::printf(fails ? "FAILED (%d)\n" : "all scenes dumped without a sanitizer report\n", fails);
     return fails ? 1 : 0;
