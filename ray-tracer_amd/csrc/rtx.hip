@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     uint32_t rays_traced = 0;  // per lane; summed in 64 bits at the end
     uint32_t wave_box = 0, wave_prim = 0;  // wave-uniform: lanes x steps of the box / primitive stage = tests performed
     uint32_t lane_box = 0;                 // box tests of this lane where they are counted per lane: the wide walk (child boxes, two to four
-                                           // per node) and the box runs of the packed LDS walk
+                                           // per node) and the hand-scheduled box runs over arrays in LDS
 #ifdef RTX_STAGE_COUNTERS
     unsigned long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // box steps, box lanes, prim steps, prim lanes, service passes, shade lanes, gen lanes, sched passes
     unsigned long long tc[4] = {0, 0, 0, 0};              // wave clocks inside the box / primitive / service stage, and in total
@@ -1378,6 +1378,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                         } while (nb * k1 >= n_fixed && nb > 0);
                     }
                     wave_box += tests;
+#if !defined(RTX_STAGE_COUNTERS) && !defined(RTX_BOX_LOOP_COMPILED)
+                } else if (!STRICT && ENTS_IN_LDS) {
+                    // fast walk over 32-byte entries in LDS: the loop below, hand-scheduled like the packed one
+                    const uint32_t k1 = P.sched_k + 1u;
+                    const uint32_t min_lanes = n_fixed == 64u ? P.box_run_min : (n_fixed + k1 - 1u) / k1;
+                    box_run_lds(box_lanes, off, st, lane_box, rc, XF ? wx.tmin : tmin, best.t, min_lanes);
+#endif
                 } else {
                     uint4 ea, eb;  // (as above: only lanes at a box read them)
                     asm("" : "=v"(ea.x), "=v"(ea.y), "=v"(ea.z), "=v"(ea.w), "=v"(eb.x), "=v"(eb.y), "=v"(eb.z), "=v"(eb.w));
@@ -1650,12 +1657,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     unsigned long long wave_rays = rays_traced;
     for (int o = 32; o > 0; o >>= 1) wave_rays += __shfl_down(wave_rays, o);
     unsigned long long wave_lane_box = lane_box;
-    if (WIDE || (PK && ENTS_IN_LDS))
-        for (int o = 32; o > 0; o >>= 1) wave_lane_box += __shfl_down(wave_lane_box, o);
+    for (int o = 32; o > 0; o >>= 1) wave_lane_box += __shfl_down(wave_lane_box, o);
     unsigned long long* const tally = reinterpret_cast<unsigned long long*>(acc);
     if (lane == 0) {
         tally[0] = wave_rays;
-        tally[1] = wave_lane_box + (unsigned long long)wave_box;  // (the wide walk and the packed LDS walk count per lane, the others per wave)
+        tally[1] = wave_lane_box + (unsigned long long)wave_box;  // (the wide walk and the box runs in LDS count per lane, the others per wave)
         tally[2] = wave_prim;
     }
     __syncthreads();

@@ -534,6 +534,63 @@ __device__ __forceinline__ void pk_box_run_lds(unsigned long long at_box, uint32
         : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
+// The same run over a copy of a fast array of 32-byte entries that starts at LDS address 0 (scenes with media or placed
+// instance primitives, whose arrays have no packed form): each step is slab_hit<SLAB_FMA> -- six fused plane distances,
+// their per-axis minima and maxima, the lane's own interval start (inside a medium's boundary query it is not the
+// caller's) -- then the next entry (hit) or the box's miss link.  A box entry is (x0 x1 y0 y1) (z0 z1 link 0): its state
+// word, 0 for a box, is the last word of the second read, so one wait per step covers both reads.
+// v[56:59] and v[60:63] hold the current entry.
+__device__ __forceinline__ void box_run_lds(unsigned long long at_box, uint32_t& off, uint32_t& st, uint32_t& lane_tests, const RayConst& rc, float tmin,
+                                            float tmax, uint32_t min_lanes) {
+    uint32_t nb;
+    unsigned long long saved;
+    float t0, t1, t2, t3, t4, t5;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n"
+        "s_mov_b64 exec, %[joined]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "ds_read_b128 v[56:59], %[off]\n"
+        "ds_read_b128 v[60:63], %[off] offset:16\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n"
+        "v_fma_f32 %[t0], v56, %[ix], %[nx]\n"
+        "v_fma_f32 %[t1], v57, %[ix], %[nx]\n"
+        "v_fma_f32 %[t2], v58, %[iy], %[ny]\n"
+        "v_fma_f32 %[t3], v59, %[iy], %[ny]\n"
+        "v_fma_f32 %[t4], v60, %[iz], %[nz]\n"
+        "v_fma_f32 %[t5], v61, %[iz], %[nz]\n"
+        "v_min_f32 v56, %[t0], %[t1]\n"
+        "v_max_f32 %[t0], %[t0], %[t1]\n"
+        "v_min_f32 v57, %[t2], %[t3]\n"
+        "v_max_f32 %[t2], %[t2], %[t3]\n"
+        "v_min_f32 v58, %[t4], %[t5]\n"
+        "v_max_f32 %[t4], %[t4], %[t5]\n"
+        "v_max_f32 v56, v56, %[tmin]\n"
+        "v_max3_f32 v56, v57, v58, v56\n"
+        "v_min3_f32 %[t0], %[t2], %[t4], %[t0]\n"
+        "v_min_f32 %[t0], %[t0], %[tmax]\n"
+        "v_cmp_nle_f32 vcc, %[t0], v56\n"
+        "v_add_u32 %[cnt], 1, %[cnt]\n"
+        "v_add_u32 %[t1], 32, %[off]\n"
+        "v_cndmask_b32 %[off], v62, %[t1], vcc\n"
+        "ds_read_b128 v[56:59], %[off]\n"
+        "ds_read_b128 v[60:63], %[off] offset:16\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_cmp_eq_u32 vcc, 0, v63\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "s_bcnt1_i32_b64 %[nb], exec\n"
+        "s_cmp_ge_u32 %[nb], %[thr]\n"
+        "s_cbranch_scc1 1b\n"
+        "s_mov_b64 exec, %[joined]\n"
+        "v_mov_b32 %[st], v63\n"
+        "s_mov_b64 exec, %[saved]\n"
+        : [off] "+v"(off), [st] "+v"(st), [cnt] "+v"(lane_tests), [nb] "=&s"(nb), [saved] "=&s"(saved), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)
+        : [ix] "v"(rc.ix), [iy] "v"(rc.iy), [iz] "v"(rc.iz), [nx] "v"(rc.nx), [ny] "v"(rc.ny), [nz] "v"(rc.nz), [tmin] "v"(tmin), [tmax] "v"(tmax),
+          [thr] "s"(min_lanes), [joined] "s"(at_box)
+        : "vcc", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
 // Reads slots of the packed array through a generic pointer (trace kernel, rare paths).
 struct SlotReader {
     const uint4* base;
