@@ -1232,34 +1232,34 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             // claim -- sits behind one test of what the pool has left.
             uint32_t n_serv = n_rest, n_fixed = 64u;
             if (__builtin_expect(pool_total - pool_next < 64u, 0)) {  // (pool_next never passes pool_total)
-            if (pool_next >= pool_total) {
-                // write out the items no lane carries a path of: the tile's sums go into the batch's partial image (each
-                // pixel of each batch has exactly one writer)
-                const uint32_t my_item = st != ST_IDLE ? slot >> 6 : 0xFFFFFFFFu;
-                for (uint32_t k = 0; k < n_slots; k++) {
-                    if (((live >> k) & 1u) == 0u || __ballot(my_item == k) != 0ull) continue;
-                    KArgs* Q = RTX_ARGS();
-                    const uint32_t txy = __builtin_amdgcn_readfirstlane(item_hdr[4u * k]), batch = __builtin_amdgcn_readfirstlane(item_hdr[4u * k + 1u]);
-                    const uint32_t px = (txy & 0xFFFFu) + (lane & 7u), py = (txy >> 16) + (lane >> 3);
-                    if (px < Q->cam.width && py < Q->cam.height) {
-                        float* dst = Q->partial + ((size_t)batch * Q->cam.height * Q->cam.width + (size_t)py * Q->cam.width + px) * 3;
-                        dst[0] = acc[k * ACC_FLOATS + lane * 3 + 0];
-                        dst[1] = acc[k * ACC_FLOATS + lane * 3 + 1];
-                        dst[2] = acc[k * ACC_FLOATS + lane * 3 + 2];
+                if (pool_next >= pool_total) {
+                    // write out the items no lane carries a path of: the tile's sums go into the batch's partial image (each
+                    // pixel of each batch has exactly one writer)
+                    const uint32_t my_item = st != ST_IDLE ? slot >> 6 : 0xFFFFFFFFu;
+                    for (uint32_t k = 0; k < n_slots; k++) {
+                        if (((live >> k) & 1u) == 0u || __ballot(my_item == k) != 0ull) continue;
+                        KArgs* Q = RTX_ARGS();
+                        const uint32_t txy = __builtin_amdgcn_readfirstlane(item_hdr[4u * k]), batch = __builtin_amdgcn_readfirstlane(item_hdr[4u * k + 1u]);
+                        const uint32_t px = (txy & 0xFFFFu) + (lane & 7u), py = (txy >> 16) + (lane >> 3);
+                        if (px < Q->cam.width && py < Q->cam.height) {
+                            float* dst = Q->partial + ((size_t)batch * Q->cam.height * Q->cam.width + (size_t)py * Q->cam.width + px) * 3;
+                            dst[0] = acc[k * ACC_FLOATS + lane * 3 + 0];
+                            dst[1] = acc[k * ACC_FLOATS + lane * 3 + 1];
+                            dst[2] = acc[k * ACC_FLOATS + lane * 3 + 2];
+                        }
+                        live &= ~(1u << k);
                     }
-                    live &= ~(1u << k);
+                    if (more && live != all_slots) RTX_CLAIM((uint32_t)__builtin_ctz(~live));  // free lanes move on to the next item
+                    if (live == 0u) break;  // nothing left anywhere
                 }
-                if (more && live != all_slots) RTX_CLAIM((uint32_t)__builtin_ctz(~live));  // free lanes move on to the next item
-                if (live == 0u) break;  // nothing left anywhere
-            }
-            const uint32_t pool_left = pool_total - pool_next;
-            // lanes the service stage has work for: every finished walk, and as many free lanes as the pool has pairs for
-            if (pool_left < 64u) {
-                const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
-                n_serv = n_rest - n_idle + min(n_idle, pool_left);
-            }
-            n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
-            if (n_fixed == 0u) continue;  // only possible while an item with a zero-depth pool drains
+                const uint32_t pool_left = pool_total - pool_next;
+                // lanes the service stage has work for: every finished walk, and as many free lanes as the pool has pairs for
+                if (pool_left < 64u) {
+                    const uint32_t n_idle = (uint32_t)__popcll(__ballot(st == ST_IDLE));
+                    n_serv = n_rest - n_idle + min(n_idle, pool_left);
+                }
+                n_fixed = n_box + n_prim + n_serv;  // lanes that have or can get work
+                if (n_fixed == 0u) continue;  // only possible while an item with a zero-depth pool drains
             }
 #ifdef RTX_STAGE_COUNTERS
             sc[7]++;
