@@ -58,6 +58,15 @@ __global__ void ops(float* out, int iters, float a, float b, unsigned long long 
             if (OP == 37) EIGHT("v_min3_f32", ", %8, %9");
             if (OP == 38) EIGHT("v_mul_legacy_f32", ", %8");
             if (OP == 39) EIGHT("v_ldexp_f32", ", %8");
+            if (OP == 40) EIGHT("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,0,0] ; ", "");
+            if (OP == 41) EIGHT("v_fma_mix_f32 %0, %8, %9, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0] ; ", "");
+            if (OP == 42) EIGHT("v_perm_b32", ", %8, %9");
+            if (OP == 43) EIGHT("v_cvt_f32_f16", "");
+            if (OP == 44) EIGHT("v_cvt_f32_ubyte2", "");
+            if (OP == 45) EIGHT("v_or_b32", ", %8");
+            if (OP == 46) EIGHT("v_max3_f32", ", %8, %9");
+            if (OP == 47) EIGHT("v_cmp_lt_f32 vcc, %0, %8 ; ", "");
+            if (OP == 48) EIGHT("v_min_f32", ", %8");
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p1.y + p2.x + p3.y;
@@ -89,5 +98,7 @@ int main() {
     R(26, "v_pk_add_f32"); R(27, "v_mul_hi_u32"); R(28, "v_alignbit_b32"); R(29, "v_xad_u32"); R(30, "v_cvt_f32_ubyte0"); R(31, "v_fract_f32");
     R(32, "v_floor_f32"); R(33, "v_sin_f32"); R(34, "v_or3_b32"); R(35, "v_and_or_b32"); R(36, "v_fma_f32 |b| -c"); R(37, "v_min3_f32");
     R(38, "v_mul_legacy_f32"); R(39, "v_ldexp_f32");
+    R(40, "v_fma_mix_f32 lo"); R(41, "v_fma_mix_f32 hi"); R(42, "v_perm_b32"); R(43, "v_cvt_f32_f16"); R(44, "v_cvt_f32_ubyte2");
+    R(45, "v_or_b32"); R(46, "v_max3_f32"); R(47, "v_cmp_lt_f32"); R(48, "v_min_f32");
     return 0;
 }
