@@ -519,8 +519,7 @@ __device__ __forceinline__ void pk_box_run_lds(unsigned long long at_box, uint32
         "ds_read_b128 v[56:59], %[off]\n"
         "ds_read_b128 v[60:63], %[off] offset:16\n"
         "s_waitcnt lgkmcnt(1)\n"
-        "v_cmp_gt_u32 vcc, %[prim], v59\n"
-        "s_and_b64 exec, exec, vcc\n"
+        "v_cmpx_gt_u32 vcc, %[prim], v59\n"
         "s_bcnt1_i32_b64 %[nb], exec\n"
         "s_cmp_ge_u32 %[nb], %[thr]\n"
         "s_cbranch_scc1 1b\n"
@@ -576,8 +575,7 @@ __device__ __forceinline__ void box_run_lds(unsigned long long at_box, uint32_t&
         "ds_read_b128 v[56:59], %[off]\n"
         "ds_read_b128 v[60:63], %[off] offset:16\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_cmp_eq_u32 vcc, 0, v63\n"
-        "s_and_b64 exec, exec, vcc\n"
+        "v_cmpx_eq_u32 vcc, 0, v63\n"
         "s_bcnt1_i32_b64 %[nb], exec\n"
         "s_cmp_ge_u32 %[nb], %[thr]\n"
         "s_cbranch_scc1 1b\n"
