@@ -480,8 +480,8 @@ __device__ __forceinline__ bool pk_slab_hit_scaled(const uint4& s0, const uint4&
 // Written out instruction by instruction because of what the loop costs around the test itself: the wave is bound by
 // instruction issue, scalar instructions included (six more of them per step cost 14 %), and the compiler's form of
 // this loop -- a mask saved, tested and restored around the step, the wave's condition kept as a lane mask -- spends
-// thirteen scalar instructions per step where four do: lanes that leave are simply taken out of EXEC, the lanes left are
-// counted from EXEC and compared with a threshold the caller derives once per run.  The two vector instructions
+// thirteen scalar instructions per step where three do: lanes that leave are taken out of EXEC by the compare that
+// finds them (v_cmpx), the lanes left are counted from EXEC and compared with a threshold the caller derives once per run.  The two vector instructions
 // between the compare that decides hit / miss and the select that consumes it (the step counter, the address of the
 // next entry) are the wait states that pair needs.
 // at_box: the wave's lanes whose state word says "box" (the caller has that mask from its own count), not empty.
