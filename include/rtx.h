@@ -62,10 +62,13 @@ enum {
     RTX_OBJ_TRANSLATE = 1, /* mesh.rs:324-354: child, f[0..3] = offset                               */
     RTX_OBJ_ROTATE_Y = 2,  /* mesh.rs:356-432: child, f[0] = sin_theta, f[1] = cos_theta              */
     RTX_OBJ_MEDIUM = 3     /* mesh.rs:627-696: child = boundary, f[0] = density, material = Isotropic, prim_id.
-                            * Narrower than the reference: the boundary may be any hittable EXCEPT one that contains
-                            * another RTX_OBJ_MEDIUM (the reference's `B: Mesh` would accept that, none of its scenes
-                            * builds it); rtx_scene_create refuses such a scene with RTX_ERR_UNSUPPORTED -- the walk
-                            * keeps one level of saved boundary-query state per ray. */
+                            * The boundary may be any hittable, one that contains further RTX_OBJ_MEDIUM objects included
+                            * (the reference's `B: Mesh`; none of its scenes builds that): the inner media's hits then
+                            * bound the outer medium as mesh.rs:635-638 has it.  Media may nest four deep -- a walk parks
+                            * one boundary-query state per enclosing medium, in device memory the scene allocates when it
+                            * nests any (60 bytes per resident lane); rtx_scene_create refuses deeper nesting with
+                            * RTX_ERR_UNSUPPORTED.  Calls that walk such a scene (trace or render) must not overlap in
+                            * time on one device copy: they would share that memory. */
 };
 typedef struct rtx_object {
     uint32_t kind;

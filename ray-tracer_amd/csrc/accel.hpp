@@ -18,8 +18,9 @@
 //                          kind 4 transform enter: word 0 = 1 translate (words 1-3 offset) | 2 rotate-y (word 1 sin,
 //                                 word 2 cos); word 4 = enclosing transform-enter entry or NONE
 //                          kind 5 transform leave: word 4 = enclosing transform-enter entry or NONE
-//                          kind 6 medium begin:    word 0 density, word 1 material, word 2 prim id, word 6 = its end
-//                          kind 7 medium end:      word 6 = its begin
+//                          kind 6 medium begin:    word 0 density, word 1 material, word 2 prim id, word 3 nesting level
+//                                                  (number of media whose boundary it lies in), word 6 = its end
+//                          kind 7 medium end:      word 0 nesting level, word 6 = its begin
 //   ENT_END                terminator appended after the last entry: the walk is complete
 // Links are entry indices while building and byte offsets after finalize().
 #pragma once
@@ -49,6 +50,7 @@ constexpr uint32_t ENT_INST = 8;
 constexpr int MAX_INST_LEVELS = 2;
 constexpr uint32_t ENT_END = 0xFFFFFFFEu;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int MAX_MED_DEPTH = 4;  // ConstantMedium boundaries nested inside one another (a walk saves one state record per enclosing medium)
 constexpr int MAX_XF_DEPTH = 64;  // nested Translate / RotateY levels accepted (the kernels walk the chain of enclosing transforms)
 
 struct Ent {
@@ -62,6 +64,7 @@ struct Threaded {
     std::vector<uint32_t> mat;   // per entry: material of a primitive / medium-end entry (what a hit there is shaded with), else NONE
     uint32_t n_boxes = 0, n_prims = 0;
     bool has_brackets = false;   // contains transform or medium entries (or ENT_INST primitives)
+    int med_levels = 0;          // deepest nesting of media: 1 = media side by side only, 2 = one inside another's boundary, ...
     bool has_frames = false;     // contains transform-enter / leave entries: a walk changes frames
     std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
     std::vector<Ent> chains;     // fast only: chain records of the ENT_INST entries (appended behind the terminator by finalize)
@@ -218,24 +221,27 @@ class Builder {
     // Emit a Translate / RotateY / ConstantMedium object: opening bracket, its child through `child_fn`, closing bracket.
     template <class F>
     bool emit_bracketed(Threaded& out, const rtx_object_t& o, uint32_t obj_index, uint32_t rank, uint32_t enclosing_xf, int xf_depth,
-                        bool in_medium, F child_fn) {
+                        int med_depth, F child_fn) {
         out.has_brackets = true;
         Ent a, b;
         std::memset(&a, 0, sizeof(a));
         std::memset(&b, 0, sizeof(b));
         uint32_t at = (uint32_t)out.ents.size();
         if (o.kind == RTX_OBJ_MEDIUM) {
-            if (in_medium) return fail("a ConstantMedium inside the boundary of another one is not supported", true);
+            if (med_depth >= MAX_MED_DEPTH) return fail("ConstantMedium boundaries nested deeper than 4 levels", true);
             if (o.material >= d.n_materials) return fail("medium material out of range");
             if (!(o.f[0] == o.f[0])) return fail("NaN medium density");
             a.w[0] = fbits(o.f[0]);
             a.w[1] = o.material;
             a.w[2] = o.prim_id;
+            out.med_levels = std::max(out.med_levels, med_depth + 1);
+            a.w[3] = (uint32_t)med_depth;  // media whose boundary this one lies in: the level its saved walk state goes to
             a.w[7] = ENT_MED_BEGIN | (obj_index << 4);
             out.ents.push_back(a);
             out.rank.push_back(rank);
             out.mat.push_back(NONE);
-            if (!child_fn(o.child, enclosing_xf, xf_depth, true)) return false;
+            if (!child_fn(o.child, enclosing_xf, xf_depth, med_depth + 1)) return false;
+            b.w[0] = (uint32_t)med_depth;
             b.w[6] = at;
             b.w[7] = ENT_MED_END | (obj_index << 4);
             out.ents[at].w[6] = (uint32_t)out.ents.size();
@@ -255,7 +261,7 @@ class Builder {
             out.ents.push_back(a);
             out.rank.push_back(0);
             out.mat.push_back(NONE);
-            if (!child_fn(o.child, at, xf_depth + 1, in_medium)) return false;
+            if (!child_fn(o.child, at, xf_depth + 1, med_depth)) return false;
             b.w[4] = enclosing_xf;
             b.w[7] = ENT_XF_POP | (obj_index << 4);
             out.ents[at].w[6] = (uint32_t)out.ents.size();
@@ -269,7 +275,7 @@ class Builder {
     // ------------------------------------------------------------------------------------------ strict
     uint32_t next_rank = 0;
     int depth = 0;
-    bool emit_strict(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+    bool emit_strict(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, int med_depth) {
         if (!check_ref(r)) return false;
         if (++depth > 4096) return fail("scene graph too deep (cycle?)");
         uint32_t k = RTX_REF_KIND(r), i = RTX_REF_INDEX(r);
@@ -285,7 +291,7 @@ class Builder {
                 out.mat.push_back(NONE);
                 out.n_boxes++;
                 // a one-element Bvh has left == right (mesh.rs:572-577): the reference tests it twice, so do we
-                ok = emit_strict(out, n.left, enclosing_xf, xf_depth, in_medium) && emit_strict(out, n.right, enclosing_xf, xf_depth, in_medium);
+                ok = emit_strict(out, n.left, enclosing_xf, xf_depth, med_depth) && emit_strict(out, n.right, enclosing_xf, xf_depth, med_depth);
                 out.ents[at].w[6] = (uint32_t)out.ents.size();
             }
         } else if (is_prim(r)) {
@@ -298,7 +304,7 @@ class Builder {
             if (o.kind == RTX_OBJ_LIST) {
                 // World::hit (mesh.rs:66-82) is a linear scan with a shrinking interval and no box test
                 if ((uint64_t)o.first + o.count > d.n_refs) ok = fail("list object exceeds refs");
-                for (uint32_t c = 0; c < o.count && ok; c++) ok = emit_strict(out, d.refs[o.first + c], enclosing_xf, xf_depth, in_medium);
+                for (uint32_t c = 0; c < o.count && ok; c++) ok = emit_strict(out, d.refs[o.first + c], enclosing_xf, xf_depth, med_depth);
             } else if (o.kind == RTX_OBJ_TRANSLATE || o.kind == RTX_OBJ_ROTATE_Y || o.kind == RTX_OBJ_MEDIUM) {
                 uint32_t rk = 0;
                 if (o.kind == RTX_OBJ_MEDIUM) {
@@ -306,8 +312,8 @@ class Builder {
                     rk = it == first_rank.end() ? (first_rank[r] = next_rank) : it->second;
                     next_rank++;
                 }
-                ok = emit_bracketed(out, o, i, rk, enclosing_xf, xf_depth, in_medium,
-                                    [&](rtx_ref_t c, uint32_t xf, int xd, bool med) { return emit_strict(out, c, xf, xd, med); });
+                ok = emit_bracketed(out, o, i, rk, enclosing_xf, xf_depth, med_depth,
+                                    [&](rtx_ref_t c, uint32_t xf, int xd, int med) { return emit_strict(out, c, xf, xd, med); });
             } else {
                 ok = fail("unknown object kind");
             }
@@ -450,7 +456,7 @@ class Builder {
         return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
     }
 
-    bool emit_fast_subtree(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+    bool emit_fast_subtree(Threaded& out, rtx_ref_t r, uint32_t enclosing_xf, int xf_depth, int med_depth) {
         std::vector<Unit> units;
         if (!collect_units(r, units, enclosing_xf == NONE)) return false;
         if (units.empty()) return fail("empty subtree");
@@ -464,11 +470,11 @@ class Builder {
             coord_range_seen = std::fmax(coord_range_seen, u.box.max_abs());
             pad_box(u.box, coord_range);
         }
-        return sah(out, units, 0, (uint32_t)units.size(), enclosing_xf, xf_depth, in_medium);
+        return sah(out, units, 0, (uint32_t)units.size(), enclosing_xf, xf_depth, med_depth);
     }
     float coord_range_seen = 0;
 
-    bool emit_unit_fast(Threaded& out, const Unit& u, bool guard_box, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+    bool emit_unit_fast(Threaded& out, const Unit& u, bool guard_box, uint32_t enclosing_xf, int xf_depth, int med_depth) {
         if (is_prim(u.ref)) {
             push_prim(out, u.ref, u.rank);
             if (u.chain != NONE) {
@@ -489,18 +495,18 @@ class Builder {
             out.mat.push_back(NONE);
             out.n_boxes++;
         }
-        bool ok = emit_bracketed(out, o, RTX_REF_INDEX(u.ref), u.rank, enclosing_xf, xf_depth, in_medium,
-                                 [&](rtx_ref_t c, uint32_t xf, int xd, bool med) { return emit_fast_subtree(out, c, xf, xd, med); });
+        bool ok = emit_bracketed(out, o, RTX_REF_INDEX(u.ref), u.rank, enclosing_xf, xf_depth, med_depth,
+                                 [&](rtx_ref_t c, uint32_t xf, int xd, int med) { return emit_fast_subtree(out, c, xf, xd, med); });
         if (at != NONE) out.ents[at].w[6] = (uint32_t)out.ents.size();
         return ok;
     }
 
     static constexpr int NBINS = 16;
     bool bare_leaves = false;  // experiment (RTX_SAH_BARE_LEAF): a leaf of one primitive gets no box of its own
-    bool sah(Threaded& out, std::vector<Unit>& units, uint32_t begin, uint32_t end, uint32_t enclosing_xf, int xf_depth, bool in_medium) {
+    bool sah(Threaded& out, std::vector<Unit>& units, uint32_t begin, uint32_t end, uint32_t enclosing_xf, int xf_depth, int med_depth) {
         const float INF = std::numeric_limits<float>::infinity();
         if (bare_leaves && end - begin == 1 && is_prim(units[begin].ref) && !out.ents.empty())
-            return emit_unit_fast(out, units[begin], false, enclosing_xf, xf_depth, in_medium);
+            return emit_unit_fast(out, units[begin], false, enclosing_xf, xf_depth, med_depth);
         Box3 bb, cb;
         bb.reset();
         cb.reset();
@@ -564,10 +570,10 @@ class Builder {
         bool ok = true;
         if (make_leaf && n > MAX_LEAF) {
             uint32_t mid = begin + n / 2;  // all centroids coincide: halve the range to bound the leaf size
-            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium) && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
+            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, med_depth) && sah(out, units, mid, end, enclosing_xf, xf_depth, med_depth);
         } else if (make_leaf) {
             std::sort(units.begin() + begin, units.begin() + end, [](const Unit& x, const Unit& y) { return x.rank < y.rank; });
-            for (uint32_t i = begin; i < end && ok; i++) ok = emit_unit_fast(out, units[i], n > 1, enclosing_xf, xf_depth, in_medium);
+            for (uint32_t i = begin; i < end && ok; i++) ok = emit_unit_fast(out, units[i], n > 1, enclosing_xf, xf_depth, med_depth);
         } else {
             const int a = best_axis;
             const float base = cb.lo[a], scale = (float)NBINS / (cb.hi[a] - cb.lo[a]);
@@ -578,9 +584,9 @@ class Builder {
             });
             uint32_t mid = (uint32_t)(midit - units.begin());
             if (mid == begin || mid == end) mid = begin + n / 2;
-            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, in_medium);
+            ok = sah(out, units, begin, mid, enclosing_xf, xf_depth, med_depth);
             const uint32_t right_at = (uint32_t)out.ents.size();
-            ok = ok && sah(out, units, mid, end, enclosing_xf, xf_depth, in_medium);
+            ok = ok && sah(out, units, mid, end, enclosing_xf, xf_depth, med_depth);
             // (children that may be visited in either order: both must be boxes, whose links say where they end)
             if (ok && out.ents[at + 1].w[7] == ENT_BOX && right_at < out.ents.size() && out.ents[right_at].w[7] == ENT_BOX) out.inner.push_back(at);
         }
@@ -1105,7 +1111,7 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) b.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTX_SAH_CTRAV")) b.C_TRAV = (float)std::atof(e);
     if (const char* e = std::getenv("RTX_SAH_BARE_LEAF")) b.bare_leaves = std::atoi(e) != 0;
-    if (!b.emit_strict(strict, d.root, NONE, 0, false)) {
+    if (!b.emit_strict(strict, d.root, NONE, 0, 0)) {
         err = b.err;
         return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
     }
@@ -1121,7 +1127,7 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     b.coord_range = std::fmax(b.coord_range, world.max_abs());
     if (!std::isfinite(b.coord_range)) { err = "non-finite scene bounds"; return RTX_ERR_INVALID; }
     if (const char* e = std::getenv("RTX_PLACE_INSTANCES")) b.place_instances = std::atoi(e) != 0;
-    if (!b.emit_fast_subtree(fast, d.root, NONE, 0, false)) {
+    if (!b.emit_fast_subtree(fast, d.root, NONE, 0, 0)) {
         err = b.err;
         return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
     }
@@ -1132,7 +1138,7 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
         b.place_instances = false;
         b.inst_chains.clear();
         fast = Threaded();
-        if (!b.emit_fast_subtree(fast, d.root, NONE, 0, false)) {
+        if (!b.emit_fast_subtree(fast, d.root, NONE, 0, 0)) {
             err = b.err;
             return b.unsupported ? RTX_ERR_UNSUPPORTED : RTX_ERR_INVALID;
         }

@@ -31,6 +31,7 @@
 #include "rtx_device.hpp"
 
 using namespace rtxd;
+static_assert(MED_MAX_DEPTH == rtx_accel::MAX_MED_DEPTH && XF_MAX_DEPTH == rtx_accel::MAX_XF_DEPTH, "the walks hold what the host-side builder accepts");
 
 // ================================================================================================ errors
 static thread_local std::string g_err;
@@ -92,6 +93,8 @@ static bool env_flag(const char* name, bool dflt) {
 }  // [0] item counter (u32); u64 words from byte 8: rays, box tests, primitive tests, then diagnostics
 
 // The scene's device data on one GPU, with the render scratch that goes with it.
+constexpr uint32_t MED_LANES_PER_CU = 2048;  // what a CU holds at most: 32 waves
+
 struct DeviceCopy {
     int device = 0;
     int n_cus = 0;
@@ -548,6 +551,15 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     s->n_perlins = d->n_perlins;
 
     s->n_images = d->n_images;
+    if (strict.med_levels > 1) {
+        // media inside a medium's boundary: room for every lane a launch can hold to park the state of the enclosing
+        // media (MED_MAX_DEPTH - 1 records of five words each)
+        const std::vector<uint32_t> room((size_t)(MED_MAX_DEPTH - 1) * 5 * MED_LANES_PER_CU * (size_t)dc->n_cus);
+        const uint32_t* p = nullptr;
+        if ((rc = upload(dc, room, &p)) != RTX_OK) return rc;
+        dc->dev.med_stack = const_cast<uint32_t*>(p);
+        dc->dev.med_lanes = MED_LANES_PER_CU * (uint32_t)dc->n_cus;
+    }
     HIP_TRY(hipMalloc((void**)&dc->counters, COUNTER_BYTES));
     HIP_TRY(hipEventCreate(&dc->ev0));
     HIP_TRY(hipEventCreate(&dc->ev1));
@@ -584,58 +596,63 @@ static uint32_t seed_word(uint64_t seed, int which) {  // the two 32-bit words t
 
 // ================================================================================================ trace
 // QUICK: primitive tests and hit record as the render kernels' fast walk evaluates them (RTX_TRAVERSAL_RENDER).
-template <bool STRICT, int SLAB, bool QUICK = false>
+// NEST: the scene holds media inside other media's boundaries.
+template <bool STRICT, int SLAB, bool QUICK = false, bool NEST = false>
 __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax, uint32_t seed0,
                                                     uint32_t seed1, rtx_hit_t* __restrict__ hits) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     const uint4* __restrict__ ents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
     const EntReader reader{ents};
-    Ray wray;
-    wray.ox = rays[i].o[0]; wray.oy = rays[i].o[1]; wray.oz = rays[i].o[2];
-    wray.dx = rays[i].d[0]; wray.dy = rays[i].d[1]; wray.dz = rays[i].d[2];
-    wray.time = rays[i].time;
-    Ray r = wray;
-    RayConst rc = ray_const<SLAB>(r);
-    Rng rng = rng_init(seed0, seed1, (uint32_t)i, 0u);  // only a ConstantMedium draws from it (mesh.rs:659)
-    WalkX x;
-    walkx_init(x, tmin);
-    Best best;
-    best.t = tmax;
-    best.ent = NO_HIT;
-    uint32_t off = 0;
-    for (;;) {
-        uint4 ea, eb;
-        reader.load(off, ea, eb);
-        if (eb.w == ENT_END) break;
-        if (eb.w != ENT_BOX && is_bracket_kind(eb.w & 15u)) {
-            bracket_step<STRICT, SLAB>(reader, ea, eb, off, r, rc, wray, best, x, tmin, rng, rank);
-        } else {
-            const uint32_t at = off;
-            off = walk_step<STRICT, SLAB, QUICK>(S, reader, ea, eb, off, r, rc, x.tmin, best, rank);
-            if (best.ent == at) x.best_xf = x.cur_xf;
+    // One lane per ray -- or, when the scene nests media and the launch is therefore no larger than the scene's parking
+    // space for their state, a lane takes every (lanes of the launch)-th ray.
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    auto med_stack = [&]() { return MedStack{S.med_stack, S.med_lanes, g}; };
+    for (size_t i = g; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Ray wray;
+        wray.ox = rays[i].o[0]; wray.oy = rays[i].o[1]; wray.oz = rays[i].o[2];
+        wray.dx = rays[i].d[0]; wray.dy = rays[i].d[1]; wray.dz = rays[i].d[2];
+        wray.time = rays[i].time;
+        Ray r = wray;
+        RayConst rc = ray_const<SLAB>(r);
+        Rng rng = rng_init(seed0, seed1, (uint32_t)i, 0u);  // only a ConstantMedium draws from it (mesh.rs:659)
+        WalkX x;
+        walkx_init(x, tmin);
+        Best best;
+        best.t = tmax;
+        best.ent = NO_HIT;
+        uint32_t off = 0;
+        for (;;) {
+            uint4 ea, eb;
+            reader.load(off, ea, eb);
+            if (eb.w == ENT_END) break;
+            if (eb.w != ENT_BOX && is_bracket_kind(eb.w & 15u)) {
+                bracket_step<STRICT, SLAB, true, NEST>(reader, ea, eb, off, r, rc, wray, best, x, med_stack, tmin, rng, rank);
+            } else {
+                const uint32_t at = off;
+                off = walk_step<STRICT, SLAB, QUICK>(S, reader, ea, eb, off, r, rc, x.tmin, best, rank);
+                if (best.ent == at) x.best_xf = x.cur_xf;
+            }
         }
+        rtx_hit_t out;
+        if (best.ent == NO_HIT) {
+            out.prim_id = RTX_MISS;
+            out.t = 0.0f;
+            out.n[0] = out.n[1] = out.n[2] = 0.0f;
+            out.uv[0] = out.uv[1] = 0.0f;
+            out.front_face = 0;
+            out.p[0] = out.p[1] = out.p[2] = 0.0f;
+        } else {
+            HitRec h = make_hit_x<true, !QUICK>(S, reader, wray, best, x.best_xf);
+            out.prim_id = h.prim_id;
+            out.t = best.t;
+            out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
+            out.uv[0] = h.u; out.uv[1] = h.v;
+            out.front_face = 1;  // Hit::new stores `front_face: true` unconditionally (mesh.rs:47)
+            out.p[0] = h.px; out.p[1] = h.py; out.p[2] = h.pz;
+        }
+        hits[i] = out;
     }
-    rtx_hit_t out;
-    if (best.ent == NO_HIT) {
-        out.prim_id = RTX_MISS;
-        out.t = 0.0f;
-        out.n[0] = out.n[1] = out.n[2] = 0.0f;
-        out.uv[0] = out.uv[1] = 0.0f;
-        out.front_face = 0;
-        out.p[0] = out.p[1] = out.p[2] = 0.0f;
-    } else {
-        HitRec h = make_hit_x<true, !QUICK>(S, reader, wray, best, x.best_xf);
-        out.prim_id = h.prim_id;
-        out.t = best.t;
-        out.n[0] = h.nx; out.n[1] = h.ny; out.n[2] = h.nz;
-        out.uv[0] = h.u; out.uv[1] = h.v;
-        out.front_face = 1;  // Hit::new stores `front_face: true` unconditionally (mesh.rs:47)
-        out.p[0] = h.px; out.p[1] = h.py; out.p[2] = h.pz;
-    }
-    hits[i] = out;
 }
 
 // The same contract over the packed form of the fast array, with the box test the render kernels use.
@@ -832,16 +849,22 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
     const DevScene& S = scene->primary.dev;
+    // (a scene that nests media parks walk state per lane: trace_kernel then strides over the rays with the lanes it has room for)
+    dim3 xgrid(S.med_stack ? std::min<unsigned>(grid.x, std::max(1u, S.med_lanes / 256u)) : grid.x);
+    const bool nest = S.med_stack != nullptr;
+#define RTX_TRACE(STRICT_, SLAB_, QUICK_)                                                                                                                    \
+    hipLaunchKernelGGL((nest ? trace_kernel<STRICT_, SLAB_, QUICK_, true> : trace_kernel<STRICT_, SLAB_, QUICK_, false>), xgrid, block, 0, st, S, rays_dev, n, \
+                       opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev)
     if (opts->traversal == RTX_TRAVERSAL_STRICT)
-        hipLaunchKernelGGL((trace_kernel<true, SLAB_STRICT>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+        RTX_TRACE(true, SLAB_STRICT, false);
     else if (opts->traversal == RTX_TRAVERSAL_FAST)
-        hipLaunchKernelGGL((trace_kernel<false, SLAB_ROBUST>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+        RTX_TRACE(false, SLAB_ROBUST, false);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->wide)  // what the render kernels walk for this scene
         hipLaunchKernelGGL((trace_wide_kernel<false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->packed)
         hipLaunchKernelGGL((trace_packed_kernel<false, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED)
-        hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+        RTX_TRACE(false, SLAB_FMA, false);
     // RTX_TRAVERSAL_RENDER: the walk of the render kernel variant a fast render of this scene launches
     else if (scene->wide)  // render_kernel<false, false, false, *, true, true>: four-child nodes
         hipLaunchKernelGGL((trace_wide_kernel<true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
@@ -854,7 +877,8 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
     else if (scene->packed)  // render_kernel<false, false, false, *, true>: half-precision boxes
         hipLaunchKernelGGL((trace_packed_kernel<true, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else  // render_kernel<false, *, *, *, false>: 32-byte entries (scenes with Translate / RotateY / ConstantMedium)
-        hipLaunchKernelGGL((trace_kernel<false, SLAB_FMA, true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev);
+        RTX_TRACE(false, SLAB_FMA, true);
+#undef RTX_TRACE
     HIP_TRY(hipGetLastError());
     return RTX_OK;
 }
@@ -944,7 +968,7 @@ extern __shared__ uint4 smem[];
 // descends into the nearest child node.
 // NOFRAMES (with XF, fast walk): the array has media brackets and / or instance primitives placed in the caller's frame but
 // no transform-enter / leave entries, so a walk never leaves the caller's frame: no second copy of the ray, no frame ids.
-template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false, bool WIDE = false, bool NOFRAMES = false>
+template <bool STRICT, bool ENTS_IN_LDS, bool XF, bool TEX, bool PK = false, bool WIDE = false, bool NOFRAMES = false, bool NEST = false>
 // Registers per variant, through the waves per SIMD the compiler must leave room for: the lean variants 64 (8 waves), the
 // bracket variants 96 (5 waves: +10 % over 4 on the Cornell scenes, three spilled registers; at 6 they spill 47 and lose
 // 20 %), the texture variants end up at 95 on their own.
@@ -952,6 +976,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     static_assert(!PK || (!STRICT && !XF), "the packed array exists for the fast walk of bracket-free scenes only");
     static_assert(!WIDE || (PK && !ENTS_IN_LDS), "the wide array is walked from HBM in place of the packed one");
     static_assert(!NOFRAMES || (XF && !STRICT), "only the fast array of a scene with brackets can be free of frames");
+    static_assert(!NEST || XF, "media nest in arrays with brackets only");
     constexpr bool FRAMES = XF && !NOFRAMES;
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     constexpr int SLAB = STRICT ? SLAB_STRICT : SLAB_FMA;
@@ -1033,6 +1058,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     // XF only: the caller's (world) ray and the bracket state of the walk (transforms, media)
     Ray wray{};
     WalkX wx{};
+    // (XF only) where this lane parks the boundary-query state of enclosing media: asked for at a medium inside a medium
+    auto med_stack = [&]() {
+        KArgs* q_ = RTX_ARGS();
+        return MedStack{q_->S.med_stack, q_->S.med_lanes, blockIdx.x * blockDim.x + threadIdx.x};
+    };
     // WIDE only: the node to visit next, the pending group of the deepest level that has one (older groups are on the
     // lane's stack in LDS, w_sp of them), and the primitives handed out by the last node
     uint32_t w_node = WIDE_NONE, w_group = 0, w_sp = 0, w_tbase = 0, w_tmask = 0;
@@ -1434,9 +1464,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                         if (XF && (NOFRAMES ? is_bracket_kind(kind15) : kind15 >= ENT_XF_PUSH)) {
                             // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
                             if constexpr (FRAMES)
-                                bracket_step<STRICT, SLAB, true>(reader, ea, eb, off, ray, rc, wray, best, wx, tmin, rng, rank);
+                                bracket_step<STRICT, SLAB, true, NEST>(reader, ea, eb, off, ray, rc, wray, best, wx, med_stack, tmin, rng, rank);
                             else
-                                bracket_step<STRICT, SLAB, false>(reader, ea, eb, off, ray, rc, ray, best, wx, tmin, rng, rank);
+                                bracket_step<STRICT, SLAB, false, NEST>(reader, ea, eb, off, ray, rc, ray, best, wx, med_stack, tmin, rng, rank);
                         } else {
                             // A primitive of an instance placed in this frame's tree (frame-less arrays only: the host places
                             // either every instance of a scene or none) is tested in its own frame, with a moved copy of the ray.
@@ -1948,8 +1978,20 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     static void (*const frameless_kernels[4])(RenderParams) = {
         render_kernel<false, false, true, false, false, false, true>, render_kernel<false, false, true, true, false, false, true>,
         render_kernel<false, true, true, false, false, false, true>,  render_kernel<false, true, true, true, false, false, true>};
+    // scenes with media inside other media's boundaries: the bracket variants that park the enclosing media's state
+    static void (*const nest_kernels[8])(RenderParams) = {
+        render_kernel<false, false, true, false, false, false, false, true>, render_kernel<false, false, true, true, false, false, false, true>,
+        render_kernel<false, true, true, false, false, false, false, true>,  render_kernel<false, true, true, true, false, false, false, true>,
+        render_kernel<true, false, true, false, false, false, false, true>,  render_kernel<true, false, true, true, false, false, false, true>,
+        render_kernel<true, true, true, false, false, false, false, true>,   render_kernel<true, true, true, true, false, false, false, true>};
+    static void (*const nest_frameless_kernels[4])(RenderParams) = {
+        render_kernel<false, false, true, false, false, false, true, true>, render_kernel<false, false, true, true, false, false, true, true>,
+        render_kernel<false, true, true, false, false, false, true, true>,  render_kernel<false, true, true, true, false, false, true, true>};
+    const bool nest = c->dev.med_stack != nullptr;
     const bool frameless = M == RTX_TRAVERSAL_FAST && scene->has_brackets && !scene->fast_has_frames;
-    void (*kern)(RenderParams) = wide ? wide_kernels[scene->has_tex ? 1 : 0]
+    void (*kern)(RenderParams) = nest && frameless ? nest_frameless_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
+                                 : nest ? nest_kernels[(M == RTX_TRAVERSAL_STRICT ? 4 : 0) | (in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
+                                 : wide ? wide_kernels[scene->has_tex ? 1 : 0]
                                  : pk ? packed_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
                                  : frameless ? frameless_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
                                     : kernels[(M == RTX_TRAVERSAL_STRICT ? 8 : 0) | (in_lds ? 4 : 0) | (scene->has_brackets ? 2 : 0) | (scene->has_tex ? 1 : 0)];
@@ -1999,6 +2041,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
                      blocks_per_cu, lds, n_slots, P.n_batches, P.batch, P.n_items);
 
     if ((rc = kernel_allow_lds((const void*)kern, c->device, lds)) != RTX_OK) return rc;
+    if (c->dev.med_stack && (uint64_t)grid.x * block.x > c->dev.med_lanes) return fail(RTX_ERR_DEVICE, "internal: more lanes than the scene's nested media have parking room for");
 
     HIP_TRY(hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(kern, grid, block, lds, st, P);
@@ -2195,6 +2238,7 @@ static int replicate(const rtx_scene* scene, DeviceCopy* r) {
         RTX_REBASE(pk_rank);
         if (p.dev.pk_shade) RTX_REBASE(pk_shade);
     }
+    if (p.dev.med_stack) RTX_REBASE(med_stack);
     if (p.dev.wnodes) {
         RTX_REBASE(wnodes);
         RTX_REBASE(wprims);

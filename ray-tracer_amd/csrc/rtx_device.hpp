@@ -59,6 +59,11 @@ struct DevScene {
     const uint4* wprims;       // 5 x uint4 per primitive
     const uint32_t* wrank;     // per slot of wprims: tie-break rank of the primitive whose record starts there
     uint32_t w_levels;         // nodes on the longest path from the root = groups a walk can have pending + 1
+    // Scenes with a ConstantMedium inside another one's boundary: where a walk parks the boundary-query state of the
+    // enclosing media (layout: MedStack), null otherwise.  One record set per lane of a launch: launches over one
+    // scene copy that overlap in time would share it.
+    uint32_t* med_stack;
+    uint32_t med_lanes;        // lanes it has room for
 };
 
 struct Ray {
@@ -796,6 +801,20 @@ struct WalkX {
     uint32_t sv_ent, sv_xf;
     float med_t1;      // NaN during the first boundary query, hit1.distance during the second
 };
+// A ConstantMedium's boundary may hold further media (mesh.rs:627-631 takes any `B: Mesh`; :635-638 then calls their
+// hit() inside the boundary queries).  WalkX holds the boundary-query state of the innermost medium a walk is inside; the
+// states of the media around it wait in DevScene::med_stack, one five-word record per nesting level and lane (the begin /
+// end entries carry their level), word j of level l of lane g at [(5 * (l - 1) + j) * lanes + g].  Memory, not
+// registers: it is touched only when a medium begins or ends inside another one.
+constexpr int MED_MAX_DEPTH = 4;  // the host rejects deeper nesting (rtx_accel::MAX_MED_DEPTH)
+struct MedStack {
+    uint32_t* base;  // DevScene::med_stack (null when the scene nests no media: no entry then has a level above 0)
+    uint32_t lanes;  // DevScene::med_lanes
+    uint32_t lane;   // this lane's index among the lanes of the launch (< lanes: checked by the host at launch)
+    __device__ __forceinline__ uint32_t* rec(uint32_t level) const {  // level of the begin / end entry, 1 <= level < MED_MAX_DEPTH
+        return base + (size_t)(5u * (min(level, (uint32_t)MED_MAX_DEPTH - 1u) - 1u)) * lanes + lane;
+    }
+};
 __device__ __forceinline__ void walkx_init(WalkX& x, float tmin) {
     x.cur_xf = XF_NONE;
     x.best_xf = XF_NONE;
@@ -914,9 +933,11 @@ __device__ __forceinline__ uint32_t walk_step(const DevScene& S, const READER& e
 // One walk step at a bracket entry (ea, eb) at byte offset off.  `ray` is the ray in the current frame, `wray` the
 // caller's ray; `main_tmin` the start of the caller's interval; the caller's interval end is the running best.
 // FRAMES = false: the array holds no transform-enter / leave entries (media only); wray is not read.
-template <bool STRICT, int SLAB, bool FRAMES = true, class READER>
+// NEST: the array holds media inside other media's boundaries; med(): the MedStack of this lane, asked for only at such a
+// medium.  (A flag, not a run-time test alone: the parking code costs the frame-less render variants ten spilled registers.)
+template <bool STRICT, int SLAB, bool FRAMES = true, bool NEST = false, class READER, class MED>
 __device__ inline void bracket_step(const READER& ents, const uint4& ea, const uint4& eb, uint32_t& off, Ray& ray, RayConst& rc, const Ray& wray,
-                                    Best& best, WalkX& x, float main_tmin, Rng& rng, const uint32_t* __restrict__ rank) {
+                                    Best& best, WalkX& x, const MED& med, float main_tmin, Rng& rng, const uint32_t* __restrict__ rank) {
     const uint32_t kind = eb.w & 15u;
     if (FRAMES && kind == ENT_XF_PUSH) {
         x.cur_xf = off;
@@ -930,6 +951,15 @@ __device__ inline void bracket_step(const READER& ents, const uint4& ea, const u
         off += ENT_BYTES;
     } else if (kind == ENT_MED_BEGIN) {
         // ConstantMedium::hit (mesh.rs:634-638): first boundary query over the whole line
+        if (NEST && ea.w != 0u) {  // inside another medium's boundary query: that query's state waits at this entry's level
+            const MedStack m = med();
+            uint32_t* s = m.rec(ea.w);
+            s[0] = __float_as_uint(x.sv_t);
+            s[m.lanes] = x.sv_ent;
+            s[2u * m.lanes] = x.sv_xf;
+            s[3u * m.lanes] = __float_as_uint(x.med_t1);
+            s[4u * m.lanes] = __float_as_uint(x.tmin);
+        }
         x.sv_t = best.t;
         x.sv_ent = best.ent;
         x.sv_xf = x.best_xf;
@@ -949,6 +979,13 @@ __device__ inline void bracket_step(const READER& ents, const uint4& ea, const u
         } else {
             bool some = false;
             float distance = 0.0f;
+            // the interval this medium's hit() was called with starts where its caller's does: the walk's own interval, or,
+            // inside another medium, the start of the boundary query that came by (mesh.rs:635 -inf, :638 hit1 + 0.0001)
+            const uint32_t level = NEST ? ea.x : 0u;
+            if (NEST && level != 0u) {
+                const MedStack m = med();
+                main_tmin = __uint_as_float(m.rec(level)[4u * m.lanes]);
+            }
             if (x.med_t1 == x.med_t1 && best.ent != NO_HIT) {  // both boundary hits exist (mesh.rs:640-665)
                 float t1 = x.med_t1, t2 = best.t;
                 if (t1 < main_tmin) t1 = main_tmin;
@@ -972,6 +1009,14 @@ __device__ inline void bracket_step(const READER& ents, const uint4& ea, const u
             x.best_xf = x.sv_xf;
             x.tmin = main_tmin;
             x.med_t1 = __builtin_nanf("");
+            if (NEST && level != 0u) {  // back in the enclosing medium's boundary query
+                const MedStack m = med();
+                const uint32_t* outer = m.rec(level);
+                x.sv_t = __uint_as_float(outer[0]);
+                x.sv_ent = outer[m.lanes];
+                x.sv_xf = outer[2u * m.lanes];
+                x.med_t1 = __uint_as_float(outer[3u * m.lanes]);
+            }
             // strict: the caller takes whatever the medium returns (mesh.rs:76-78, :611-616); fast: closest hit, reference tie order
             if (some && (STRICT || in_range<false>(distance, main_tmin, best, off, rank))) {
                 best.t = distance;

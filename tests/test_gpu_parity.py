@@ -497,3 +497,81 @@ def test_instanced_scene_renders_match_oracle(render, oracle, scenes, name, spp)
     # at this size (the oracle's own seed-to-seed difference of the mean is 0.5 - 1.4 %)
     _, fast = cam.render(scene, seed=6, traversal=render.TRAVERSAL_FAST, want_accum=True)
     assert abs(fast.mean() - ref.mean()) < 0.04 * abs(ref.mean()), name
+
+
+def _media_in_media(scene, which):
+    """Scenes whose ConstantMedium boundaries hold further media (mesh.rs:627-631 takes any `B: Mesh`; none of the
+    reference's own scenes builds this, so the oracle's recursion is the only statement of what must come out)."""
+    white, red = scene.Lambertian.rgb(0.73, 0.73, 0.73), scene.Lambertian.rgb(0.65, 0.05, 0.05)
+    w = scene.World()
+    # (a flat floor: on a sphere of radius 1000 a bounce origin that differs in the last place -- a free-flight distance goes
+    # through logf -- decides now and then whether a grazing ray meets the floor again, which would blur the frame comparison)
+    w.push(scene.Quad((-40, -1.5, -40), (80, 0, 0), (0, 0, 80), white))
+    w.push(scene.Sphere.stationary((3.2, 0, -1), 1.0, red))
+    if which == "direct":  # a medium IS the boundary of another one
+        inner = scene.ConstantMedium.from_color(scene.Sphere.stationary((0, 0, 0), 1.4, white), 0.9, (0.9, 0.9, 0.2))
+        w.push(scene.ConstantMedium.from_color(inner, 0.4, (0.1, 0.1, 0.1)))
+    elif which == "list":  # the boundary is a list of a surface, two media and a cube
+        b = scene.World()
+        b.push(scene.Sphere.stationary((0, 0, 0), 1.8, white))
+        b.push(scene.ConstantMedium.from_color(scene.Sphere.stationary((0.6, 0.2, 0.3), 0.8, white), 2.5, (0.2, 0.9, 0.2)))
+        b.push(scene.ConstantMedium.from_color(scene.Cube((-1.2, -0.9, -0.6), (-0.3, 0.1, 0.7), white), 1.5, (0.2, 0.2, 0.9)))
+        b.push(scene.Cube((-0.2, -1.2, 0.9), (0.5, -0.6, 1.5), red))
+        w.push(scene.ConstantMedium.from_color(b, 0.35, (0.8, 0.8, 0.8)))
+    elif which == "deep":  # four levels, the deepest the walk holds, each boundary a list of the next medium and a shell
+        m = scene.Sphere.stationary((0.2, 0.1, 0), 0.5, white)
+        for k in range(4):
+            b = scene.World()
+            b.push(scene.ConstantMedium.from_color(m, 1.2 - 0.25 * k, (0.9 - 0.2 * k, 0.3 + 0.2 * k, 0.5)) if k else m)
+            b.push(scene.Sphere.stationary((0.1 * k, 0, 0), 0.8 + 0.35 * k, white))
+            m = b
+        w.push(scene.ConstantMedium.from_color(m, 0.25, (0.7, 0.7, 0.7)))
+    else:  # "instanced": media inside a medium inside Translate(RotateY(.)), with an instance inside the inner boundary
+        b = scene.World()
+        b.push(scene.Cube((-1.5, -1.0, -1.2), (1.5, 1.2, 1.2), white))
+        b.push(scene.ConstantMedium.from_color(scene.Translate(scene.RotateY(scene.Cube((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), white), 30.0), (0.3, 0.0, 0.2)),
+                                               2.0, (0.9, 0.5, 0.1)))
+        w.push(scene.Translate(scene.RotateY(scene.ConstantMedium.from_color(b, 0.3, (0.6, 0.6, 0.9)), -20.0), (-0.2, 0.1, 0.0)))
+    cfg = scene.CameraConfig(width=160, height=120, samples_per_pixel=16, max_depth=12, vfov=38.0, lookfrom=(0.5, 1.5, 8.0), lookat=(0.4, 0, 0))
+    return cfg, scene.Bvh(w)
+
+
+@pytest.mark.parametrize("which", ["direct", "list", "deep", "instanced"])
+def test_media_nested_in_media_match_oracle(render, oracle, scene, which):
+    """ConstantMedium::hit calls `boundary.hit` twice (mesh.rs:635-638) on whatever mesh the boundary is -- another medium
+    included, whose own two queries then run inside the outer one's, against the interval the outer query hands down.  The
+    walk keeps the innermost medium's query state in registers and the enclosing ones' per nesting level.  Strict walk =
+    the oracle's recursion hit for hit (same visiting order, hence the same free-flight draws; logf differs by ulps);
+    mirror-stream frames equal; the fast walk is the same estimator in another visiting order."""
+    cfg, bvh = _media_in_media(scene, which)
+    om, gs = oracle.OracleMesh(bvh), render.Scene(bvh)
+    prim = oracle.OracleCamera(cfg).center_rays(0.5)
+    sec = _secondary_rays(oracle, cfg, bvh, 30_000, 5)
+    kinds = set()
+    for label, rays in (("primary", prim), ("secondary", sec)):
+        want = om.trace(rays, seed=31, mirror=True)
+        got = gs.trace(rays, traversal=render.TRAVERSAL_STRICT, seed=31)
+        same = got["prim_id"] == want["prim_id"]
+        assert np.mean(same) > 0.9999, (which, label, float(np.mean(same)))  # measured: no differing id in 200 000 rays per scene
+        hit = same & (want["prim_id"] != MISS)
+        assert np.allclose(got["t"][hit], want["t"][hit], rtol=1e-5, atol=1e-6), (which, label)
+        assert np.allclose(got["p"][hit], want["p"][hit], rtol=1e-5, atol=1e-4), (which, label)
+        assert np.allclose(got["n"][hit], want["n"][hit], rtol=1e-5, atol=1e-6), (which, label)
+        kinds |= set(np.unique(want["prim_id"]).tolist())
+        # the fast walks visit in another order (other draws), yet a ray that no medium's boundary box touches cannot differ,
+        # and the shares of rays that end in each medium agree
+        for mode in (render.TRAVERSAL_FAST, render.TRAVERSAL_RENDER):
+            fast = gs.trace(rays, traversal=mode, seed=31)
+            for pid in np.unique(want["prim_id"]):
+                a, b = np.mean(fast["prim_id"] == pid), np.mean(want["prim_id"] == pid)
+                assert abs(a - b) < 0.012 + 0.05 * b, (which, label, mode, int(pid), float(a), float(b))
+    assert len(kinds) >= 4, kinds  # both surfaces, the miss and the outermost medium (inner media only ever bound the outer one)
+    ref, _ = oracle.OracleCamera(cfg).render(om, seed=9, rng_kind=1)
+    cam = render.Camera(cfg)
+    _, acc = cam.render(gs, seed=9, traversal=render.TRAVERSAL_STRICT, want_accum=True)
+    rel = np.abs(acc - ref) / (np.abs(ref) + 5e-2 * cfg.samples_per_pixel)
+    assert np.median(rel) < 1e-6, (which, float(np.median(rel)))
+    assert np.mean(rel < 1e-3) > 0.999, (which, float(np.mean(rel < 1e-3)))  # measured: 0.99995 - 1.0
+    assert abs(acc.mean() - ref.mean()) < 1e-3 * abs(ref.mean()), which
+    _, fast = cam.render(gs, seed=10, traversal=render.TRAVERSAL_FAST, want_accum=True)
+    assert abs(fast.mean() - ref.mean()) < 0.03 * abs(ref.mean()), which

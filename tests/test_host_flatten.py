@@ -115,17 +115,31 @@ def test_triangle_mesh_flattens_like_the_oracle(render, oracle, scenes):
 
 def test_unsupported_scene_graphs_are_refused_not_mis_rendered(render, scene):
     """What the traversal data cannot express is refused when it is built (RTX_ERR_UNSUPPORTED), host side, no GPU needed:
-    a ConstantMedium inside the boundary of another one (mesh.rs:627-696 would nest them), and transforms nested deeper
-    than the kernels' limit of 64."""
+    ConstantMedium boundaries nested more than four deep (mesh.rs:627-631 takes any `B: Mesh`; a walk keeps one saved
+    boundary-query state per enclosing medium), and transforms nested deeper than the kernels' limit of 64."""
     white = scene.Lambertian.rgb(0.7, 0.7, 0.7)
     ball = scene.Sphere.stationary((0, 0, 0), 1.0, white)
-    inner = scene.ConstantMedium.from_color(ball, 0.5, (1, 1, 1))
-    w = scene.World()
-    w.push(scene.ConstantMedium.from_color(inner, 0.1, (0, 0, 0)))
-    w.push(scene.Sphere.stationary((3, 0, 0), 1.0, white))
-    with pytest.raises(render.RtxError) as e:
-        render.Scene(scene.Bvh(w), upload=False).traversal_dump(render.TRAVERSAL_FAST)
-    assert e.value.code == render.RTX_ERR_UNSUPPORTED and "ConstantMedium" in str(e.value)
+
+    def nested(levels):
+        m = ball
+        for k in range(levels):
+            m = scene.ConstantMedium.from_color(m, 0.1 * (k + 1), (1, 1, 1))
+        w = scene.World()
+        w.push(m)
+        w.push(scene.Sphere.stationary((3, 0, 0), 1.0, white))
+        return scene.Bvh(w)
+
+    for mode in (render.TRAVERSAL_STRICT, render.TRAVERSAL_FAST):
+        with pytest.raises(render.RtxError) as e:
+            render.Scene(nested(5), upload=False).traversal_dump(mode)
+        assert e.value.code == render.RTX_ERR_UNSUPPORTED and "ConstantMedium" in str(e.value)
+        # four levels are accepted; every begin / end entry carries its nesting level (word 3 / word 0), 0 = outermost
+        ents, _ = render.Scene(nested(4), upload=False).traversal_dump(mode)
+        kind = ents[:, 7] & 15
+        assert sorted(ents[kind == 6, 3].tolist()) == [0, 1, 2, 3] and sorted(ents[kind == 7, 0].tolist()) == [0, 1, 2, 3]
+        for b in np.flatnonzero(kind == 6):
+            end = ents[b, 6] // 32  # (links are byte offsets of 32-byte entries)
+            assert (ents[end, 7] & 15) == 7 and ents[end, 0] == ents[b, 3] and ents[end, 6] == 32 * b
     obj = ball
     for k in range(65):
         obj = scene.Translate(obj, (0.01, 0.0, 0.0)) if k % 2 else scene.RotateY(obj, 1.0)
