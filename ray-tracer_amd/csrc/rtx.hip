@@ -49,7 +49,7 @@ constexpr uint32_t MAX_ITEM_SLOTS_HOST = 8;  // items in flight per wave, upper 
 // Tuning knobs, read from the environment once per process.
 struct Knobs {
     uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, planar_lds_max, perlin_lds, waves_per_block,
-        blocks_per_cu, debug, wide, w_mix, sched_k_wide, xcd_items;
+        blocks_per_cu, debug, wide, w_mix, sched_k_wide, xcd_items, skip_root;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -77,6 +77,7 @@ static const Knobs& knobs() {
         x.w_mix = u("RTX_W_MIX", 3);
         x.sched_k_wide = std::max(1u, u("RTX_SCHED_K_WIDE", 3));
         x.xcd_items = u("RTX_XCD_ITEMS", 1);
+        x.skip_root = u("RTX_SKIP_ROOT", 1);
         return x;
     }();
     return k;
@@ -599,7 +600,7 @@ static uint32_t seed_word(uint64_t seed, int which) {  // the two 32-bit words t
 // NEST: the scene holds media inside other media's boundaries.
 template <bool STRICT, int SLAB, bool QUICK = false, bool NEST = false>
 __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax, uint32_t seed0,
-                                                    uint32_t seed1, rtx_hit_t* __restrict__ hits) {
+                                                    uint32_t seed1, rtx_hit_t* __restrict__ hits, uint32_t start_off) {
     constexpr int M = STRICT ? RTX_TRAVERSAL_STRICT : RTX_TRAVERSAL_FAST;
     const uint4* __restrict__ ents = S.ents[M];
     const uint32_t* __restrict__ rank = S.rank[M];
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
         Best best;
         best.t = tmax;
         best.ent = NO_HIT;
-        uint32_t off = 0;
+        uint32_t off = start_off;  // (0, or behind the root box where a render of the scene starts its walks)
         for (;;) {
             uint4 ea, eb;
             reader.load(off, ea, eb);
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
 //                 tests, reciprocal-multiplied normals (RTX_TRAVERSAL_RENDER).
 template <bool RENDER, bool SCALED>
 __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
-                                                            rtx_hit_t* __restrict__ hits) {
+                                                            rtx_hit_t* __restrict__ hits, uint32_t start_off) {
     static_assert(RENDER || !SCALED, "only the render walk runs in scaled ray parameters");
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
     Best best;
     best.t = SCALED ? tmax * PK_T_SCALE : tmax;
     best.ent = NO_HIT;
-    uint32_t off = 0;
+    uint32_t off = start_off;
     for (;;) {
         const uint4 e = slots.at(off);
         if (e.w == ENT_END) break;
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256) void trace_packed_kernel(DevScene S, const rtx
 // record through pk_render_prim / pk_render_hit -- reading entries from LDS by byte offset.
 extern __shared__ uint4 trace_smem[];
 __global__ __launch_bounds__(256) void trace_packed_lds_kernel(DevScene S, const rtx_ray_t* __restrict__ rays, size_t n, float tmin, float tmax,
-                                                                rtx_hit_t* __restrict__ hits) {
+                                                                rtx_hit_t* __restrict__ hits, uint32_t start_off) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const u32x4 lds_u4;
     for (uint32_t k = threadIdx.x; k < S.pk_slots; k += blockDim.x) trace_smem[k] = S.pk[k];
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(256) void trace_packed_lds_kernel(DevScene S, const
     Best best;
     best.t = tmax * PK_T_SCALE;
     best.ent = NO_HIT;
-    uint32_t off = 0, st = live ? slot(0u).w : ENT_END;
+    uint32_t off = start_off, st = live ? slot(start_off).w : ENT_END;
     for (;;) {
         const bool at_prim = st >= PK_PRIM && st < ENT_END;
         if (__ballot(st < ENT_END) == 0ull) break;
@@ -838,6 +839,22 @@ __global__ __launch_bounds__(256) void trace_wide_kernel(DevScene S, const rtx_r
     hits[i] = out;
 }
 
+// Every ray of a render starts at the camera or on a surface.  When the camera stands inside the fast array's root box no
+// ray can miss that box (the surfaces are inside it by construction), so the walks start at the entry behind it: the
+// root's first child, whose miss link leads to the second and on to the end as if the root had been entered.  Only cost
+// changes, never a hit: a box test can only cull.  Returns the byte offset a fast walk of this scene starts at.
+static uint32_t walk_start_off(const rtx_scene* scene, const float center[3], bool packed_form) {
+    if (knobs().skip_root == 0u || scene->fast_indexed.ents.size() < 2 || scene->fast_indexed.ents[0].w[7] != rtx_accel::ENT_BOX) return 0u;
+    const rtx_accel::Ent& root = scene->fast_indexed.ents[0];
+    for (int a = 0; a < 3; a++) {
+        float lo, hi;
+        std::memcpy(&lo, &root.w[2 * a], 4);
+        std::memcpy(&hi, &root.w[2 * a + 1], 4);
+        if (!(center[a] > lo && center[a] < hi)) return 0u;
+    }
+    return packed_form ? (scene->pk_half ? 16u : 32u) : 32u;
+}
+
 static int kernel_allow_lds(const void* kern, int device, size_t lds);
 
 extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_dev, size_t n, const rtx_trace_opts_t* opts, rtx_hit_t* hits_dev,
@@ -852,19 +869,22 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
     // (a scene that nests media parks walk state per lane: trace_kernel then strides over the rays with the lanes it has room for)
     dim3 xgrid(S.med_stack ? std::min<unsigned>(grid.x, std::max(1u, S.med_lanes / 256u)) : grid.x);
     const bool nest = S.med_stack != nullptr;
-#define RTX_TRACE(STRICT_, SLAB_, QUICK_)                                                                                                                    \
+    // RTX_TRAVERSAL_RENDER starts its walks where the last render of the scene started them (behind the root box when that
+    // render's camera stood inside it)
+    const uint32_t start = opts->traversal == RTX_TRAVERSAL_RENDER && scene->primary.view_valid ? walk_start_off(scene, scene->primary.view, scene->packed) : 0u;
+#define RTX_TRACE(STRICT_, SLAB_, QUICK_, START_)                                                                                                                    \
     hipLaunchKernelGGL((nest ? trace_kernel<STRICT_, SLAB_, QUICK_, true> : trace_kernel<STRICT_, SLAB_, QUICK_, false>), xgrid, block, 0, st, S, rays_dev, n, \
-                       opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev)
+                       opts->tmin, opts->tmax, seed_word(opts->seed, 0), seed_word(opts->seed, 1), hits_dev, START_)
     if (opts->traversal == RTX_TRAVERSAL_STRICT)
-        RTX_TRACE(true, SLAB_STRICT, false);
+        RTX_TRACE(true, SLAB_STRICT, false, 0u);
     else if (opts->traversal == RTX_TRAVERSAL_FAST)
-        RTX_TRACE(false, SLAB_ROBUST, false);
+        RTX_TRACE(false, SLAB_ROBUST, false, 0u);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->wide)  // what the render kernels walk for this scene
         hipLaunchKernelGGL((trace_wide_kernel<false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED && scene->packed)
-        hipLaunchKernelGGL((trace_packed_kernel<false, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+        hipLaunchKernelGGL((trace_packed_kernel<false, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev, 0u);
     else if (opts->traversal == RTX_TRAVERSAL_FAST_FUSED)
-        RTX_TRACE(false, SLAB_FMA, false);
+        RTX_TRACE(false, SLAB_FMA, false, 0u);
     // RTX_TRAVERSAL_RENDER: the walk of the render kernel variant a fast render of this scene launches
     else if (scene->wide)  // render_kernel<false, false, false, *, true, true>: four-child nodes
         hipLaunchKernelGGL((trace_wide_kernel<true>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
@@ -872,12 +892,12 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
         const size_t lds = (size_t)S.pk_slots * 16;
         int rc = kernel_allow_lds((const void*)trace_packed_lds_kernel, scene->primary.device, lds);
         if (rc != RTX_OK) return rc;
-        hipLaunchKernelGGL(trace_packed_lds_kernel, grid, block, lds, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+        hipLaunchKernelGGL(trace_packed_lds_kernel, grid, block, lds, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev, start);
     }
     else if (scene->packed)  // render_kernel<false, false, false, *, true>: half-precision boxes
-        hipLaunchKernelGGL((trace_packed_kernel<true, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev);
+        hipLaunchKernelGGL((trace_packed_kernel<true, false>), grid, block, 0, st, S, rays_dev, n, opts->tmin, opts->tmax, hits_dev, start);
     else  // render_kernel<false, *, *, *, false>: 32-byte entries (scenes with Translate / RotateY / ConstantMedium)
-        RTX_TRACE(false, SLAB_FMA, true);
+        RTX_TRACE(false, SLAB_FMA, true, start);
 #undef RTX_TRACE
     HIP_TRY(hipGetLastError());
     return RTX_OK;
@@ -933,6 +953,7 @@ struct RenderParams {
     uint32_t n_slots;     // items in flight per wave (tile accumulators per wave): 1 = no overlap of items
     uint32_t xcd_parts;   // scenes in HBM: 0 = one item counter, 1 = a counter per band of tile columns, 2 = per range of owned tiles
     uint32_t wide_stack_u4;  // WIDE variants: where the block's walk stacks start in LDS, in 16-byte units (behind accumulators and tables)
+    uint32_t start_off;   // byte offset of the entry a walk starts at: 0, or the entry behind the root box when no ray of the call can miss that box
     uint32_t* item_counter;
     unsigned long long* ray_counter;  // [0] rays, [1] box tests, [2] primitive tests (then diagnostics)
     float* partial;       // [n_batches][H][W][3]
@@ -1136,8 +1157,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
         };
     };
     uint32_t root_st = 0u;  // queue of the first entry (wave-uniform); a wide walk starts at the root node
+    const uint32_t start_off = WIDE ? 0u : P.start_off;
     if (!WIDE) {
-        RTX_LOAD_STATE(0u, root_st);
+        RTX_LOAD_STATE(start_off, root_st);
         root_st = __builtin_amdgcn_readfirstlane(root_st);
     }
 #define RTX_BEGIN_WALK()                 \
@@ -1151,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             walkx_init(wx, tmin);         \
         }                                \
         rays_traced++;                   \
-        off = 0;                         \
+        off = start_off;                 \
         st = root_st;                    \
         if (WIDE) {                      \
             w_node = 0u;                 \
@@ -1974,6 +1996,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     static void (*const wide_kernels[2])(RenderParams) = {render_kernel<false, false, false, false, true, true>, render_kernel<false, false, false, true, true, true>};
     P.box_run_min = (64u + K.sched_k) / (K.sched_k + 1u);
     P.xcd_parts = K.xcd_items == 0u ? 0u : (P.tile_world == 1u ? 1u : 2u);
+    P.start_off = M == RTX_TRAVERSAL_FAST && !wide ? walk_start_off(scene, cam->center, pk) : 0u;
     if (wide) P.sched_k = K.sched_k_wide;  // (a wide step serves nodes and primitives alike: it pays to leave it for other stages sooner)
     static void (*const frameless_kernels[4])(RenderParams) = {
         render_kernel<false, false, true, false, false, false, true>, render_kernel<false, false, true, true, false, false, true>,
