@@ -575,3 +575,50 @@ def test_media_nested_in_media_match_oracle(render, oracle, scene, which):
     assert abs(acc.mean() - ref.mean()) < 1e-3 * abs(ref.mean()), which
     _, fast = cam.render(gs, seed=10, traversal=render.TRAVERSAL_FAST, want_accum=True)
     assert abs(fast.mean() - ref.mean()) < 0.03 * abs(ref.mean()), which
+
+
+def test_walk_start_behind_the_root_box(render, oracle, scene):
+    """A fast render whose camera stands inside the root box of the scene starts its walks at the entry behind that box
+    (no ray of such a render can miss it), one whose camera stands outside starts at the root: the same scene from both
+    sides gives the strict walk's frame either way, the kernel's own count says one box test per ray was saved, and the
+    trace that follows a render (RTX_TRAVERSAL_RENDER starts where the render did) still equals the oracle -- also for
+    rays that start outside the box the skipped test would have culled them at, and for a root that is a leaf."""
+    grey, red = scene.Lambertian.rgb(0.6, 0.6, 0.6), scene.Lambertian.rgb(0.7, 0.2, 0.2)
+    capi = importlib.import_module("ray-tracer_amd.capi")
+
+    def world(n):
+        w = scene.World()
+        w.push(scene.Sphere.stationary((0, -100.5, -1), 100.0, grey))  # (the "inside" camera stands in a corner of its box, off the sphere)
+        for k in range(n - 1):
+            w.push(scene.Sphere.stationary((-1.5 + 0.75 * k, 0.0, -1.5 - 0.1 * k), 0.35, red))
+        return scene.Bvh(w)
+
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 6):
+        bvh = world(n)
+        om = oracle.OracleMesh(bvh)
+        per_ray = {}
+        for where, lookfrom in (("inside", (90.0, -10.0, 80.0)), ("outside", (0.0, 250.0, 300.0))):
+            cfg = scene.CameraConfig(width=96, height=64, samples_per_pixel=8, max_depth=8, vfov=50.0, lookfrom=lookfrom, lookat=(0, -3, -1.5))
+            gs, cam = render.Scene(bvh), render.Camera(cfg)
+            _, a, st = cam.render(gs, seed=4, traversal=render.TRAVERSAL_FAST, want_accum=True, want_stats=True)
+            _, b = cam.render(gs, seed=4, traversal=render.TRAVERSAL_STRICT, want_accum=True)
+            rel = np.abs(a - b) / (np.abs(b) + 1e-2)
+            assert np.median(rel) < 1e-6 and np.mean(rel < 1e-4) > 0.999, (n, where, float(np.mean(rel < 1e-4)))
+            per_ray[where] = st.box_tests / st.rays
+            cam.render(gs, seed=4, traversal=render.TRAVERSAL_FAST)  # (the trace below follows a fast render)
+            rays = np.zeros(4000, dtype=capi.RAY_DTYPE)
+            rays["o"] = rng.uniform(-3, 3, size=(4000, 3)).astype(F) + np.array([0, 1.5, -1], F)
+            rays["o"][:500] += np.array([0, 400, 0], F)  # far outside every box
+            rays["d"] = rng.normal(size=(4000, 3)).astype(F)
+            rays["time"] = 0.5
+            want = om.trace(rays)
+            got = gs.trace(rays, traversal=render.TRAVERSAL_RENDER)
+            assert np.array_equal(got["prim_id"], want["prim_id"]), (n, where)
+            hit = want["prim_id"] != MISS
+            assert np.allclose(got["t"][hit], want["t"][hit], rtol=1e-5, atol=0), (n, where)
+        # from inside every ray saves the root's test, from outside the walk starts at the root
+        if n == 1:  # (root = the leaf's box: [box][sphere][end])
+            assert per_ray["inside"] == 0.0 and per_ray["outside"] == 1.0, per_ray
+        elif n == 2:  # (root over two leaf boxes: both are met by every walk that starts behind the root)
+            assert per_ray["inside"] == 2.0 and 1.0 < per_ray["outside"] <= 3.0, per_ray
