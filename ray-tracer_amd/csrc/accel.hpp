@@ -733,6 +733,8 @@ class Reorder {
 // rounded to nearest and the half extent is rounded UP from what is needed to cover the given box around the rounded
 // centre; where a value does not fit a half (beyond 65504) the axis gets an infinite extent around 0 and never culls.
 constexpr uint32_t PK_PRIM = 0x10000000u;
+constexpr uint32_t PK_PAD_FLAG = 0x08000000u;   // in a sphere's tag: a pad slot follows the entry
+constexpr uint32_t PK_INDEX_MASK = 0x07FFFFFFu;  // the index part of a tag
 constexpr uint32_t PK_SLOT_BYTES = 16u;
 
 static inline uint16_t f16_nearest(float f) {  // IEEE binary16, round to nearest even; overflow -> inf, NaN -> NaN
@@ -791,11 +793,26 @@ struct Packed {
 // planar: 5 x 4 floats per quad / triangle as the device keeps them ((Q,d) (u,mat) (v,0) (n,0) (w,0)), quads first, and
 // planar_id: their prim ids in the same order.  `t` is a fast array in entry-index form (before finalize).
 // Returns false when it holds brackets (or is too large for 28-bit slot links).
+// Arrays with float boxes (the ones walked from LDS): every entry is 32 bytes or 80, so without further ado the first
+// slot of every entry stands at an even multiple of 16 bytes and the second at an odd one -- and a 16-byte LDS read of one
+// wave instruction, which goes for the same slot of every lane's entry, uses only every other group of four banks.  A
+// one-slot *pad* behind every pk_pad_every()-th sphere shifts what follows by 16 bytes, so that entries of both
+// parities exist and a read spreads over all banks.  Nobody reads a pad: links lead to the entry behind it, and the
+// sphere in front of it says in its tag (PK_PAD_FLAG) that it is three slots long.  RTX_PK_PAD=0: no pads.
+static inline uint32_t pk_pad_every() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("RTX_PK_PAD");  // (measured on the benchmark scene: 2 to 32 all gain, flat between 8 and 16)
+        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 8u;
+    }();
+    return v;
+}
 static inline size_t packed_slots(const Threaded& t, bool half_boxes) {  // terminator included
-    size_t slots = 1;
+    size_t slots = 1, spheres = 0;
+    const uint32_t pad = half_boxes ? 0u : pk_pad_every();
     for (const Ent& e : t.ents) {
         const uint32_t kind = e.w[7] == ENT_BOX ? ENT_BOX : (e.w[7] & 15u);
         slots += kind == ENT_BOX ? (half_boxes ? 1 : 2) : kind == ENT_SPHERE ? 2 : 5;
+        if (kind == ENT_SPHERE && pad != 0u && ++spheres % pad == 0) slots++;
     }
     return slots;
 }
@@ -804,12 +821,15 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
     if (t.has_brackets) return false;
     const size_t n = t.ents.size();
     std::vector<uint32_t> first(n + 1);
-    size_t slots = 0;
+    std::vector<uint32_t> pads;  // slot indices of the pads (see pk_pad_every)
+    const uint32_t pad_every = half_boxes ? 0u : pk_pad_every();
+    size_t slots = 0, spheres = 0;
     for (size_t i = 0; i < n; i++) {
         first[i] = (uint32_t)slots;
         const uint32_t w7 = t.ents[i].w[7];
         const uint32_t kind = w7 == ENT_BOX ? ENT_BOX : (w7 & 15u);
         slots += kind == ENT_BOX ? (half_boxes ? 1 : 2) : kind == ENT_SPHERE ? 2 : 5;
+        if (kind == ENT_SPHERE && pad_every != 0u && ++spheres % pad_every == 0) pads.push_back((uint32_t)slots++);
     }
     first[n] = (uint32_t)slots;
     slots += 1;  // terminator
@@ -858,6 +878,7 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
             continue;
         }
         const uint32_t kind = w7 & 15u, index = w7 >> 4;
+        if (index > PK_INDEX_MASK) return false;
         out.rank[first[i]] = t.rank[i];
         out.mat[first[i]] = t.mat[i];
         if (kind == ENT_SPHERE) {
@@ -875,6 +896,7 @@ static inline bool pack(const Threaded& t, const float* planar, const uint32_t* 
         }
     }
     out.words[4 * (size_t)first[n] + 3] = ENT_END;
+    for (uint32_t p : pads) out.words[4 * (size_t)(p - 2u) + 3] |= PK_PAD_FLAG;  // (the sphere in front of the pad)
     return true;
 }
 

@@ -31,6 +31,7 @@
 #include "rtx_device.hpp"
 
 using namespace rtxd;
+static_assert(PK_PRIM == rtx_accel::PK_PRIM && PK_PAD_FLAG == rtx_accel::PK_PAD_FLAG && PK_INDEX_MASK == rtx_accel::PK_INDEX_MASK, "one tag layout on both sides");
 static_assert(MED_MAX_DEPTH == rtx_accel::MAX_MED_DEPTH && XF_MAX_DEPTH == rtx_accel::MAX_XF_DEPTH, "the walks hold what the host-side builder accepts");
 
 // ================================================================================================ errors
@@ -1547,7 +1548,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                         // large scenes keep no per-slot table: the entry names its material (a sphere through its record)
                         const auto slots = slot_of(best.ent);
                         const uint4 first = slots(0);
-                        const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(Q->S.sph[2u * (first.w & (PK_PRIM - 1u)) + 1u].w) : slots(2).w;
+                        const uint32_t m = (first.w >> 28) == ENT_SPHERE ? __float_as_uint(Q->S.sph[2u * (first.w & PK_INDEX_MASK) + 1u].w) : slots(2).w;
                         s0 = Q->S.mat_recs[2u * m];
                         s1 = Q->S.mat_recs[2u * m + 1u];
                     } else {

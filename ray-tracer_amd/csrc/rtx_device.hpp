@@ -409,6 +409,8 @@ __device__ __forceinline__ HitRec make_hit(const DevScene& S, const uint4& ea, c
 // 16-byte slots (layout: accel.hpp).  Word 3 of an entry's first slot is the walk state of a lane standing there:
 // below PK_PRIM = box (and its miss link, in slots), kind << 28 | index = primitive, ENT_END = walk complete.
 constexpr uint32_t PK_PRIM = 0x10000000u;
+constexpr uint32_t PK_PAD_FLAG = 0x08000000u;   // in a sphere's tag: a one-slot pad follows the entry (layout: accel.hpp)
+constexpr uint32_t PK_INDEX_MASK = 0x07FFFFFFu;  // the index part of a tag
 constexpr uint32_t PK_SLOT = 16u;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
@@ -610,7 +612,7 @@ __device__ __forceinline__ uint32_t pk_prim_test(const uint4& s0, const uint4& s
     if (kind == ENT_SPHERE) {
         // slots (c0.xyz, tag) (dc.xyz, r) in the word order sphere_test reads an unpacked entry
         sphere_test<false, 4, QUICK>(make_uint4(s0.x, s0.y, s0.z, s1.x), make_uint4(s1.y, s1.z, s1.w, 0u), r, rc, tmin, best, off, rank);
-        return 2u * PK_SLOT;
+        return (2u + ((s0.w / PK_PAD_FLAG) & 1u)) * PK_SLOT;  // (a pad slot may follow: accel.hpp, pk_pad_every)
     }
     // slots (n, tag) (Q, d) (u, material) (v, prim id) (w, 0) -> records 0 Q  1 u  2 v  3 n  4 w
     planar_test_ld<false, 4, QUICK>(
@@ -622,7 +624,7 @@ __device__ __forceinline__ uint32_t pk_prim_test(const uint4& s0, const uint4& s
 template <bool WANT_UV, bool EXACT, bool IDS, class LD>
 __device__ __forceinline__ HitRec pk_make_hit(const DevScene& S, LD ld, const Ray& r, float t) {
     const uint4 s0 = ld(0), s1 = ld(1);
-    const uint32_t kind = s0.w >> 28, pi = s0.w & (PK_PRIM - 1u);
+    const uint32_t kind = s0.w >> 28, pi = s0.w & PK_INDEX_MASK;
     HitRec h;
     h.px = r.ox + r.dx * t;  // Ray::get_point (lib.rs:27-29)
     h.py = r.oy + r.dy * t;

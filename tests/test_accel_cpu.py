@@ -200,7 +200,7 @@ def walk_packed(slots, rank, ray, half_boxes, tmin=F(0.001)):
                     root = (h + sq) / a
                 if accept(root, i):
                     best_t, best = root, i
-            i += 2
+            i += 2 + ((tag >> 27) & 1)  # (a pad slot may follow a sphere: its tag says so)
         else:
             n, q, dd, u, v, w = fl[i, :3], fl[i + 1, :3], fl[i + 1, 3], fl[i + 2, :3], fl[i + 3, :3], fl[i + 4, :3]
             denom = dot3(n[0], n[1], n[2], d[0], d[1], d[2])
@@ -218,7 +218,7 @@ def walk_packed(slots, rank, ray, half_boxes, tmin=F(0.001)):
         return MISS, INF, False, steps
     tag = int(slots[best, 3])
     if (tag >> 28) == 1:
-        return tag & (PK_PRIM - 1), best_t, True, steps
+        return tag & 0x07FFFFFF, best_t, True, steps
     return int(slots[best + 3, 3]), best_t, False, steps
 
 
