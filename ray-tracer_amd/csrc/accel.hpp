@@ -64,6 +64,7 @@ struct Threaded {
     std::vector<uint32_t> mat;   // per entry: material of a primitive / medium-end entry (what a hit there is shaded with), else NONE
     uint32_t n_boxes = 0, n_prims = 0;
     bool has_brackets = false;   // contains transform or medium entries (or ENT_INST primitives)
+    bool has_bare = false;       // some subtree stands without a box of its own (see Builder::never_culls): not a strict binary tree of boxes
     int med_levels = 0;          // deepest nesting of media: 1 = media side by side only, 2 = one inside another's boundary, ...
     bool has_frames = false;     // contains transform-enter / leave entries: a walk changes frames
     std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
@@ -503,6 +504,18 @@ class Builder {
 
     static constexpr int NBINS = 16;
     bool bare_leaves = false;  // experiment (RTX_SAH_BARE_LEAF): a leaf of one primitive gets no box of its own
+    // A box that contains every surface of the scene contains the origin of every bounce ray, and such a ray cannot miss
+    // it: its test is a step that never culls.  (The ground sphere of radius 1000 under a scene two units high: its padded
+    // box reaches above everything that stands on it.)  A single primitive under such a box stands in its parent's
+    // sequence without it.  Top-level frame only, never the root (whose test the render skips by itself when the camera
+    // is inside), and only for arrays that keep the threaded form: the wide form is built from a strict binary tree.
+    bool drop_unculling = false;
+    Box3 scene_tight;          // tight bounds of everything (world frame)
+    bool never_culls(const Box3& b) const {
+        for (int a = 0; a < 3; a++)
+            if (!(b.lo[a] < scene_tight.lo[a] && b.hi[a] > scene_tight.hi[a])) return false;
+        return true;
+    }
     bool sah(Threaded& out, std::vector<Unit>& units, uint32_t begin, uint32_t end, uint32_t enclosing_xf, int xf_depth, int med_depth) {
         const float INF = std::numeric_limits<float>::infinity();
         if (bare_leaves && end - begin == 1 && is_prim(units[begin].ref) && !out.ents.empty())
@@ -519,6 +532,11 @@ class Builder {
             }
         }
         const uint32_t n = end - begin;
+        if (drop_unculling && n == 1 && is_prim(units[begin].ref) && units[begin].chain == NONE && enclosing_xf == NONE && med_depth == 0 && !out.ents.empty() &&
+            never_culls(bb)) {
+            out.has_bare = true;
+            return emit_unit_fast(out, units[begin], false, enclosing_xf, xf_depth, med_depth);
+        }
         const uint32_t at = (uint32_t)out.ents.size();
         const float b6[6] = {bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1], bb.lo[2], bb.hi[2]};
         out.ents.push_back(box_entry(b6, 0));
@@ -623,6 +641,7 @@ class Reorder {
         dst.n_prims = src.n_prims;
         dst.has_brackets = src.has_brackets;
         dst.has_frames = src.has_frames;
+        dst.has_bare = src.has_bare;
         dst.chains = src.chains;
         dst.inner.clear();
         for (uint32_t j = 0; j < n;) j = place(j, view);
@@ -1128,7 +1147,9 @@ static inline void finalize(Threaded& t) {
 }
 
 // Build both arrays.  Returns RTX_OK or an error status with `err` set.
-static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, Threaded& fast_indexed, float& coord_range, std::string& err) {
+// drop_unculling: see Builder::never_culls (the caller asks for it when the fast array will be walked in its threaded form).
+static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& fast, Threaded& fast_indexed, float& coord_range, std::string& err,
+                        bool drop_unculling = false) {
     Builder b(d);
     if (const char* e = std::getenv("RTX_SAH_MAXLEAF")) b.MAX_LEAF = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RTX_SAH_CTRAV")) b.C_TRAV = (float)std::atof(e);
@@ -1148,6 +1169,8 @@ static inline int build(const rtx_scene_desc_t& d, Threaded& strict, Threaded& f
     }
     b.coord_range = std::fmax(b.coord_range, world.max_abs());
     if (!std::isfinite(b.coord_range)) { err = "non-finite scene bounds"; return RTX_ERR_INVALID; }
+    b.scene_tight = world;
+    b.drop_unculling = drop_unculling;
     if (const char* e = std::getenv("RTX_PLACE_INSTANCES")) b.place_instances = std::atoi(e) != 0;
     if (!b.emit_fast_subtree(fast, d.root, NONE, 0, 0)) {
         err = b.err;

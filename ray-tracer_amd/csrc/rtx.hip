@@ -50,7 +50,7 @@ constexpr uint32_t MAX_ITEM_SLOTS_HOST = 8;  // items in flight per wave, upper 
 // Tuning knobs, read from the environment once per process.
 struct Knobs {
     uint32_t view_order, items_per_wave, max_batches, sched_k, w_prim, w_serv, sched_kp, item_slots, lds_ents_max, planar_lds_max, perlin_lds, waves_per_block,
-        blocks_per_cu, debug, wide, w_mix, sched_k_wide, xcd_items, skip_root;
+        blocks_per_cu, debug, wide, w_mix, sched_k_wide, xcd_items, skip_root, drop_unculling;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -79,6 +79,7 @@ static const Knobs& knobs() {
         x.sched_k_wide = std::max(1u, u("RTX_SCHED_K_WIDE", 3));
         x.xcd_items = u("RTX_XCD_ITEMS", 1);
         x.skip_root = u("RTX_SKIP_ROOT", 1);
+        x.drop_unculling = u("RTX_DROP_UNCULLING", 1);
         return x;
     }();
     return k;
@@ -303,6 +304,25 @@ static void build_planar(const rtx_scene_desc_t& desc, std::vector<float4>& plan
     }
 }
 
+// Builds the traversal arrays of a scene.  A fast array that will be walked in its threaded form (small scenes: from LDS)
+// drops the boxes that cannot cull (rtx_accel::Builder::never_culls); one that turns out to need half-precision boxes and
+// with them the wide form, which is made from a strict binary tree of boxes, is built again without that.
+static int build_arrays(const rtx_scene_desc_t& d, rtx_accel::Threaded& strict, rtx_accel::Threaded& fast, rtx_accel::Threaded& indexed, float& range,
+                        std::string& err) {
+    const Knobs& K = knobs();
+    const size_t estimate = 64 * (size_t)d.n_spheres + 112 * ((size_t)d.n_quads + d.n_tris);  // a box and an entry per primitive
+    const bool drop = K.drop_unculling != 0u && estimate <= K.lds_ents_max;
+    int rc = rtx_accel::build(d, strict, fast, indexed, range, err, drop);
+    if (rc == RTX_OK && indexed.has_bare && !indexed.has_brackets &&
+        (rtx_accel::packed_slots(indexed, false) * 16 > K.lds_ents_max || env_flag("RTX_PACKED_HALF", false))) {
+        strict = rtx_accel::Threaded();
+        fast = rtx_accel::Threaded();
+        indexed = rtx_accel::Threaded();
+        rc = rtx_accel::build(d, strict, fast, indexed, range, err, false);
+    }
+    return rc;
+}
+
 extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal, const float* view, float grow, uint32_t* entries_out,
                                   uint32_t* rank_out, size_t capacity, size_t* n_entries) {
     if (!n_entries) return fail(RTX_ERR_INVALID, "null argument");
@@ -312,7 +332,7 @@ extern "C" int rtx_traversal_dump(const rtx_scene_desc_t* d, uint32_t traversal,
     rtx_accel::Threaded strict, fast, indexed;
     std::string err;
     float range = 0.0f;
-    rc = rtx_accel::build(*d, strict, fast, indexed, range, err);
+    rc = build_arrays(*d, strict, fast, indexed, range, err);
     if (rc != RTX_OK) return fail(rc, err);
     if (traversal == RTX_TRAVERSAL_FAST_FUSED) {
         // the packed form: 4 words per 16-byte slot, rank per slot
@@ -406,7 +426,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     DeviceCopy* dc = &s->primary;
     rtx_accel::Threaded strict, fast;
     std::string err;
-    int rc = rtx_accel::build(*d, strict, fast, s->fast_indexed, s->coord_range, err);
+    int rc = build_arrays(*d, strict, fast, s->fast_indexed, s->coord_range, err);
     if (rc != RTX_OK) return fail(rc, err);
     if (strict.has_brackets) s->has_brackets = true;  // transforms / media need the bracket-aware kernel variant
     s->fast_has_frames = fast.has_frames;
