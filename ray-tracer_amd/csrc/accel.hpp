@@ -606,7 +606,7 @@ class Builder {
             const uint32_t right_at = (uint32_t)out.ents.size();
             ok = ok && sah(out, units, mid, end, enclosing_xf, xf_depth, med_depth);
             // (children that may be visited in either order: both must be boxes, whose links say where they end)
-            if (ok && out.ents[at + 1].w[7] == ENT_BOX && right_at < out.ents.size() && out.ents[right_at].w[7] == ENT_BOX) out.inner.push_back(at);
+            if (ok && out.ents[at + 1].w[7] == ENT_BOX && out.ents[at + 1].w[6] == right_at && right_at < out.ents.size() && out.ents[right_at].w[7] == ENT_BOX) out.inner.push_back(at);
         }
         out.ents[at].w[6] = (uint32_t)out.ents.size();
         return ok;
