@@ -488,7 +488,9 @@ class Builder {
         }
         const rtx_object_t& o = d.objects[RTX_REF_INDEX(u.ref)];
         uint32_t at = NONE;
-        if (guard_box) {  // a bracketed object is a whole subtree: never enter it unless its own box is hit
+        // a bracketed object is a whole subtree: never enter it unless its own box is hit -- unless no ray can miss that
+        // box (never_culls: a medium that fills the scene)
+        if (guard_box && !(drop_unculling && enclosing_xf == NONE && never_culls(u.box))) {
             at = (uint32_t)out.ents.size();
             const float b6[6] = {u.box.lo[0], u.box.hi[0], u.box.lo[1], u.box.hi[1], u.box.lo[2], u.box.hi[2]};
             out.ents.push_back(box_entry(b6, 0));
@@ -507,7 +509,8 @@ class Builder {
     // A box that contains every surface of the scene contains the origin of every bounce ray, and such a ray cannot miss
     // it: its test is a step that never culls.  (The ground sphere of radius 1000 under a scene two units high: its padded
     // box reaches above everything that stands on it.)  A single primitive under such a box stands in its parent's
-    // sequence without it.  Top-level frame only, never the root (whose test the render skips by itself when the camera
+    // sequence without it (also the boundary of a medium that fills the scene: its two queries start inside it like any
+    // other ray).  Top-level frame only, never the root (whose test the render skips by itself when the camera
     // is inside), and only for arrays that keep the threaded form: the wide form is built from a strict binary tree.
     bool drop_unculling = false;
     Box3 scene_tight;          // tight bounds of everything (world frame)
@@ -532,8 +535,7 @@ class Builder {
             }
         }
         const uint32_t n = end - begin;
-        if (drop_unculling && n == 1 && is_prim(units[begin].ref) && units[begin].chain == NONE && enclosing_xf == NONE && med_depth == 0 && !out.ents.empty() &&
-            never_culls(bb)) {
+        if (drop_unculling && n == 1 && is_prim(units[begin].ref) && units[begin].chain == NONE && enclosing_xf == NONE && !out.ents.empty() && never_culls(bb)) {
             out.has_bare = true;
             return emit_unit_fast(out, units[begin], false, enclosing_xf, xf_depth, med_depth);
         }

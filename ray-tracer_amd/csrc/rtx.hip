@@ -311,7 +311,9 @@ static int build_arrays(const rtx_scene_desc_t& d, rtx_accel::Threaded& strict, 
                         std::string& err) {
     const Knobs& K = knobs();
     const size_t estimate = 64 * (size_t)d.n_spheres + 112 * ((size_t)d.n_quads + d.n_tris);  // a box and an entry per primitive
-    const bool drop = K.drop_unculling != 0u && estimate <= K.lds_ents_max;
+    bool brackets = false;  // (a scene with Translate / RotateY / ConstantMedium keeps the threaded form whatever its size)
+    for (uint32_t i = 0; i < d.n_objects; i++) brackets = brackets || d.objects[i].kind != RTX_OBJ_LIST;
+    const bool drop = K.drop_unculling != 0u && (estimate <= K.lds_ents_max || brackets);
     int rc = rtx_accel::build(d, strict, fast, indexed, range, err, drop);
     if (rc == RTX_OK && indexed.has_bare && !indexed.has_brackets &&
         (rtx_accel::packed_slots(indexed, false) * 16 > K.lds_ents_max || env_flag("RTX_PACKED_HALF", false))) {
