@@ -471,7 +471,33 @@ class Builder {
             coord_range_seen = std::fmax(coord_range_seen, u.box.max_abs());
             pad_box(u.box, coord_range);
         }
-        return sah(out, units, 0, (uint32_t)units.size(), enclosing_xf, xf_depth, med_depth);
+        // Units whose box no ray of the scene can miss (never_culls: a ground sphere whose padded box reaches over
+        // everything, a medium that fills the scene) are kept out of the tree: inside it they would stretch every box on
+        // the way down to them to their own size, and none of those boxes could cull either.  They stand right behind the
+        // root, without boxes of their own, and the tree of the others follows as the root's last child.
+        const uint32_t n_units = (uint32_t)units.size();
+        if (drop_unculling && enclosing_xf == NONE && med_depth == 0 && out.ents.empty() && n_units > 1) {
+            const auto rest = std::stable_partition(units.begin(), units.end(), [&](const Unit& u) { return u.chain == NONE && never_culls(u.box); });
+            const uint32_t n_fill = (uint32_t)(rest - units.begin());
+            if (n_fill > 0 && n_fill < n_units) {
+                Box3 bb;
+                bb.reset();
+                for (const Unit& u : units) bb.grow(u.box);
+                const float b6[6] = {bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1], bb.lo[2], bb.hi[2]};
+                out.ents.push_back(box_entry(b6, 0));
+                out.rank.push_back(0);
+                out.mat.push_back(NONE);
+                out.n_boxes++;
+                out.has_bare = true;
+                bool ok = true;
+                for (uint32_t i = 0; i < n_fill && ok; i++) ok = emit_unit_fast(out, units[i], false, enclosing_xf, xf_depth, med_depth);
+                ok = ok && sah(out, units, n_fill, n_units, enclosing_xf, xf_depth, med_depth);
+                out.ents[0].w[6] = (uint32_t)out.ents.size();
+                return ok;
+            }
+            std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.rank < b.rank; });
+        }
+        return sah(out, units, 0, n_units, enclosing_xf, xf_depth, med_depth);
     }
     float coord_range_seen = 0;
 
