@@ -18,7 +18,8 @@
 //                          kind 4 transform enter: word 0 = 1 translate (words 1-3 offset) | 2 rotate-y (word 1 sin,
 //                                 word 2 cos); word 4 = enclosing transform-enter entry or NONE
 //                          kind 5 transform leave: word 4 = enclosing transform-enter entry or NONE
-//                          kind 6 medium begin:    word 0 density, word 1 material, word 2 prim id, word 3 nesting level
+//                          kind 6 medium begin:    word 0 density, word 1 material, word 2 prim id, word 3 nesting level, word 4 = 1 when
+//                                                  its boundary is the one sphere entry behind it
 //                                                  (number of media whose boundary it lies in), word 6 = its end
 //                          kind 7 medium end:      word 0 nesting level, word 6 = its begin
 //   ENT_END                terminator appended after the last entry: the walk is complete
@@ -65,6 +66,7 @@ struct Threaded {
     uint32_t n_boxes = 0, n_prims = 0;
     bool has_brackets = false;   // contains transform or medium entries (or ENT_INST primitives)
     bool has_bare = false;       // some subtree stands without a box of its own (see Builder::never_culls): not a strict binary tree of boxes
+    bool sphere_media = false;   // some medium's boundary is a single sphere (its begin entry says so in word 4)
     int med_levels = 0;          // deepest nesting of media: 1 = media side by side only, 2 = one inside another's boundary, ...
     bool has_frames = false;     // contains transform-enter / leave entries: a walk changes frames
     std::vector<uint32_t> inner; // fast only: boxes whose two children are boxes that may be visited in either order
@@ -243,6 +245,11 @@ class Builder {
             out.mat.push_back(NONE);
             if (!child_fn(o.child, enclosing_xf, xf_depth, med_depth + 1)) return false;
             b.w[0] = (uint32_t)med_depth;
+            // (the boundary is one sphere, nothing else: the fast walk then makes both boundary queries in one step)
+            if (out.ents.size() == (size_t)at + 2 && out.ents[at + 1].w[7] != ENT_BOX && (out.ents[at + 1].w[7] & 15u) == ENT_SPHERE) {
+                out.ents[at].w[4] = 1u;
+                out.sphere_media = true;
+            }
             b.w[6] = at;
             b.w[7] = ENT_MED_END | (obj_index << 4);
             out.ents[at].w[6] = (uint32_t)out.ents.size();
@@ -670,6 +677,7 @@ class Reorder {
         dst.has_brackets = src.has_brackets;
         dst.has_frames = src.has_frames;
         dst.has_bare = src.has_bare;
+        dst.sphere_media = src.sphere_media;
         dst.chains = src.chains;
         dst.inner.clear();
         for (uint32_t j = 0; j < n;) j = place(j, view);

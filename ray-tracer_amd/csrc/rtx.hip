@@ -134,6 +134,7 @@ struct rtx_scene {
     uint32_t n_images = 0;
     bool has_tex = false;       // scene uses image or noise textures (uv evaluation, Perlin tables)
     bool has_brackets = false;  // scene uses Translate / RotateY / ConstantMedium
+    bool media_extras = false;  // media inside media, or media bounded by one sphere: rendered and traced by the NEST variants
     bool fast_has_frames = false;  // ... and its fast array still holds transform-enter / leave entries (instances whose
                                    // primitives could not be placed in the enclosing frame's tree)
     // the fast array in entry-index form: re-ordered for a viewpoint when a render asks for it
@@ -432,6 +433,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
     if (rc != RTX_OK) return fail(rc, err);
     if (strict.has_brackets) s->has_brackets = true;  // transforms / media need the bracket-aware kernel variant
     s->fast_has_frames = fast.has_frames;
+    s->media_extras = strict.med_levels > 1 || fast.sphere_media;
 
     HIP_TRY(hipGetDevice(&dc->device));
     hipDeviceProp_t prop;
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256) void trace_kernel(DevScene S, const rtx_ray_t*
             reader.load(off, ea, eb);
             if (eb.w == ENT_END) break;
             if (eb.w != ENT_BOX && is_bracket_kind(eb.w & 15u)) {
-                bracket_step<STRICT, SLAB, true, NEST>(reader, ea, eb, off, r, rc, wray, best, x, med_stack, tmin, rng, rank);
+                bracket_step<STRICT, SLAB, true, NEST, QUICK>(reader, ea, eb, off, r, rc, wray, best, x, med_stack, tmin, rng, rank);
             } else {
                 const uint32_t at = off;
                 off = walk_step<STRICT, SLAB, QUICK>(S, reader, ea, eb, off, r, rc, x.tmin, best, rank);
@@ -891,7 +893,7 @@ extern "C" int rtx_trace_device(const rtx_scene_t* scene, const rtx_ray_t* rays_
     const DevScene& S = scene->primary.dev;
     // (a scene that nests media parks walk state per lane: trace_kernel then strides over the rays with the lanes it has room for)
     dim3 xgrid(S.med_stack ? std::min<unsigned>(grid.x, std::max(1u, S.med_lanes / 256u)) : grid.x);
-    const bool nest = S.med_stack != nullptr;
+    const bool nest = scene->media_extras;
     // RTX_TRAVERSAL_RENDER starts its walks where the last render of the scene started them (behind the root box when that
     // render's camera stood inside it)
     const uint32_t start = opts->traversal == RTX_TRAVERSAL_RENDER && scene->primary.view_valid ? walk_start_off(scene, scene->primary.view, scene->packed) : 0u;
@@ -1509,9 +1511,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
                         if (XF && (NOFRAMES ? is_bracket_kind(kind15) : kind15 >= ENT_XF_PUSH)) {
                             // transform enter / leave, medium begin / end (mesh.rs:324-432, :627-696)
                             if constexpr (FRAMES)
-                                bracket_step<STRICT, SLAB, true, NEST>(reader, ea, eb, off, ray, rc, wray, best, wx, med_stack, tmin, rng, rank);
+                                bracket_step<STRICT, SLAB, true, NEST, !STRICT>(reader, ea, eb, off, ray, rc, wray, best, wx, med_stack, tmin, rng, rank);
                             else
-                                bracket_step<STRICT, SLAB, false, NEST>(reader, ea, eb, off, ray, rc, ray, best, wx, med_stack, tmin, rng, rank);
+                                bracket_step<STRICT, SLAB, false, NEST, !STRICT>(reader, ea, eb, off, ray, rc, ray, best, wx, med_stack, tmin, rng, rank);
                         } else {
                             // A primitive of an instance placed in this frame's tree (frame-less arrays only: the host places
                             // either every instance of a scene or none) is tested in its own frame, with a moved copy of the ray.
@@ -2033,7 +2035,7 @@ static int render_accumulate_on(rtx_scene* scene, DeviceCopy* c, const rtx_camer
     static void (*const nest_frameless_kernels[4])(RenderParams) = {
         render_kernel<false, false, true, false, false, false, true, true>, render_kernel<false, false, true, true, false, false, true, true>,
         render_kernel<false, true, true, false, false, false, true, true>,  render_kernel<false, true, true, true, false, false, true, true>};
-    const bool nest = c->dev.med_stack != nullptr;
+    const bool nest = scene->media_extras;
     const bool frameless = M == RTX_TRAVERSAL_FAST && scene->has_brackets && !scene->fast_has_frames;
     void (*kern)(RenderParams) = nest && frameless ? nest_frameless_kernels[(in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]
                                  : nest ? nest_kernels[(M == RTX_TRAVERSAL_STRICT ? 4 : 0) | (in_lds ? 2 : 0) | (scene->has_tex ? 1 : 0)]

@@ -932,12 +932,30 @@ __device__ __forceinline__ uint32_t walk_step(const DevScene& S, const READER& e
     return off + ENT_BYTES;
 }
 
+// The part of ConstantMedium::hit behind its two boundary queries (mesh.rs:640-665): the boundary hits t1, t2 clipped to
+// the interval [t_start, t_end) the medium was called with, the free-flight draw, the hit distance.  false: no hit.
+__device__ __forceinline__ bool medium_flight(float t1, float t2, float t_start, float t_end, float medium_density, const Ray& ray, Rng& rng, float& distance) {
+    if (t1 < t_start) t1 = t_start;
+    if (t2 > t_end) t2 = t_end;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    const float ray_length = __builtin_sqrtf(dot3(ray.dx, ray.dy, ray.dz, ray.dx, ray.dy, ray.dz));
+    const float inside = (t2 - t1) * ray_length;
+    const float density = -1.0f / medium_density;
+    const float hit_distance = density * logf(rng_f32(rng));
+    if (hit_distance > inside) return false;
+    distance = t1 + hit_distance / ray_length;
+    return true;
+}
+
 // One walk step at a bracket entry (ea, eb) at byte offset off.  `ray` is the ray in the current frame, `wray` the
 // caller's ray; `main_tmin` the start of the caller's interval; the caller's interval end is the running best.
 // FRAMES = false: the array holds no transform-enter / leave entries (media only); wray is not read.
-// NEST: the array holds media inside other media's boundaries; med(): the MedStack of this lane, asked for only at such a
-// medium.  (A flag, not a run-time test alone: the parking code costs the frame-less render variants ten spilled registers.)
-template <bool STRICT, int SLAB, bool FRAMES = true, bool NEST = false, class READER, class MED>
+// NEST: the array holds media inside other media's boundaries, or media whose boundary is one sphere (both get code
+// that scenes without them should not carry: the parking code costs the frame-less render variants ten spilled registers,
+// the one-step sphere boundary three); med(): the MedStack of this lane, asked for only at a medium inside a medium.
+// QUICK: how the walk this step belongs to evaluates its sphere tests (the one-sphere boundary below uses the same).
+template <bool STRICT, int SLAB, bool FRAMES = true, bool NEST = false, bool QUICK = false, class READER, class MED>
 __device__ inline void bracket_step(const READER& ents, const uint4& ea, const uint4& eb, uint32_t& off, Ray& ray, RayConst& rc, const Ray& wray,
                                     Best& best, WalkX& x, const MED& med, float main_tmin, Rng& rng, const uint32_t* __restrict__ rank) {
     const uint32_t kind = eb.w & 15u;
@@ -951,6 +969,33 @@ __device__ inline void bracket_step(const READER& ents, const uint4& ea, const u
         ray = xf_chain_ray(ents, x.cur_xf, wray);
         rc = ray_const<SLAB>(ray);
         off += ENT_BYTES;
+    } else if (!STRICT && NEST && kind == ENT_MED_BEGIN && eb.x != 0u) {
+        // A medium whose boundary is one sphere (the entry behind this one; the fast builder says so in word 4): both
+        // boundary queries (mesh.rs:635-638: the whole line, then from just behind the first hit) are that sphere's test
+        // with those two intervals, made here in one step instead of five trips through the entries.  The interval the
+        // medium is called with is the walk's current one: x.tmin (the caller's start, or inside another medium the
+        // start of the query that came by) to the running best.
+        uint4 sa, sb;
+        ents.load(off + ENT_BYTES, sa, sb);
+        const uint32_t end_off = eb.z;
+        Best q1;
+        q1.t = __builtin_inff();
+        q1.ent = NO_HIT;
+        sphere_test<false, 5, QUICK>(sa, sb, ray, rc, -__builtin_inff(), q1, off + ENT_BYTES, rank);
+        if (q1.ent != NO_HIT) {
+            Best q2;
+            q2.t = __builtin_inff();
+            q2.ent = NO_HIT;
+            sphere_test<false, 5, QUICK>(sa, sb, ray, rc, q1.t + 0.0001f, q2, off + ENT_BYTES, rank);
+            float distance = 0.0f;
+            if (q2.ent != NO_HIT && medium_flight(q1.t, q2.t, x.tmin, best.t, as_f(ea.x), ray, rng, distance) &&
+                in_range<false>(distance, x.tmin, best, end_off, rank)) {
+                best.t = distance;
+                best.ent = end_off;
+                x.best_xf = x.cur_xf;
+            }
+        }
+        off = end_off + ENT_BYTES;
     } else if (kind == ENT_MED_BEGIN) {
         // ConstantMedium::hit (mesh.rs:634-638): first boundary query over the whole line
         if (NEST && ea.w != 0u) {  // inside another medium's boundary query: that query's state waits at this entry's level
@@ -989,22 +1034,9 @@ __device__ inline void bracket_step(const READER& ents, const uint4& ea, const u
                 main_tmin = __uint_as_float(m.rec(level)[4u * m.lanes]);
             }
             if (x.med_t1 == x.med_t1 && best.ent != NO_HIT) {  // both boundary hits exist (mesh.rs:640-665)
-                float t1 = x.med_t1, t2 = best.t;
-                if (t1 < main_tmin) t1 = main_tmin;
-                if (t2 > x.sv_t) t2 = x.sv_t;
-                if (!(t1 >= t2)) {
-                    if (t1 < 0.0f) t1 = 0.0f;
-                    uint4 ba, bb;
-                    ents.load(eb.z, ba, bb);
-                    const float ray_length = __builtin_sqrtf(dot3(ray.dx, ray.dy, ray.dz, ray.dx, ray.dy, ray.dz));
-                    const float inside = (t2 - t1) * ray_length;
-                    const float density = -1.0f / as_f(ba.x);
-                    const float hit_distance = density * logf(rng_f32(rng));
-                    if (!(hit_distance > inside)) {
-                        distance = t1 + hit_distance / ray_length;
-                        some = true;
-                    }
-                }
+                uint4 ba, bb;
+                ents.load(eb.z, ba, bb);
+                some = medium_flight(x.med_t1, best.t, main_tmin, x.sv_t, as_f(ba.x), ray, rng, distance);
             }
             best.t = x.sv_t;
             best.ent = x.sv_ent;
