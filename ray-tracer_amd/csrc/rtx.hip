@@ -314,14 +314,19 @@ static int build_arrays(const rtx_scene_desc_t& d, rtx_accel::Threaded& strict, 
     const size_t estimate = 64 * (size_t)d.n_spheres + 112 * ((size_t)d.n_quads + d.n_tris);  // a box and an entry per primitive
     bool brackets = false;  // (a scene with Translate / RotateY / ConstantMedium keeps the threaded form whatever its size)
     for (uint32_t i = 0; i < d.n_objects; i++) brackets = brackets || d.objects[i].kind != RTX_OBJ_LIST;
-    const bool drop = K.drop_unculling != 0u && (estimate <= K.lds_ents_max || brackets);
-    int rc = rtx_accel::build(d, strict, fast, indexed, range, err, drop);
+    const bool threaded = estimate <= K.lds_ents_max || brackets;  // (what is walked in the threaded form; else the wide form, most likely)
+    const bool drop = K.drop_unculling != 0u && threaded;
+    // In a threaded array a quad or triangle test costs about five box steps, and the builder prices it so (leaves of
+    // several of them rarely pay); the wide form fetches the primitives of a leaf in one go and keeps the plain price.
+    const uint32_t max_leaf = 4u;
+    const float planar_cost = threaded ? 5.0f : 1.0f;
+    int rc = rtx_accel::build(d, strict, fast, indexed, range, err, drop, max_leaf, planar_cost);
     if (rc == RTX_OK && indexed.has_bare && !indexed.has_brackets &&
         (rtx_accel::packed_slots(indexed, false) * 16 > K.lds_ents_max || env_flag("RTX_PACKED_HALF", false))) {
         strict = rtx_accel::Threaded();
         fast = rtx_accel::Threaded();
         indexed = rtx_accel::Threaded();
-        rc = rtx_accel::build(d, strict, fast, indexed, range, err, false);
+        rc = rtx_accel::build(d, strict, fast, indexed, range, err, false, 4u, 1.0f);
     }
     return rc;
 }
