@@ -545,7 +545,7 @@ class Builder {
     // box reaches above everything that stands on it.)  A single primitive under such a box stands in its parent's
     // sequence without it (also the boundary of a medium that fills the scene: its two queries start inside it like any
     // other ray).  Top-level frame only, never the root (whose test the render skips by itself when the camera
-    // is inside), and only for arrays that keep the threaded form: the wide form is built from a strict binary tree.
+    // is inside).  The wide form takes the primitives that stand right behind the root as a list of its own (Wide::n_first).
     bool drop_unculling = false;
     Box3 scene_tight;          // tight bounds of everything (world frame)
     bool never_culls(const Box3& b) const {
@@ -990,6 +990,8 @@ struct Wide {
     std::vector<uint32_t> rank;   // per slot: tie-break rank of the primitive whose record starts there
     std::vector<uint32_t> mat;    // per slot: its material, NONE elsewhere
     uint32_t levels = 0;          // nodes on the longest path from the root
+    uint32_t n_first = 0;         // primitives every walk tests before it visits the root node: the first n_first records of
+                                  // `prims` (units no ray can miss, which the builder keeps out of the tree)
     size_t n_nodes() const { return nodes.size() / WIDE_NODE_WORDS; }
     size_t n_slots() const { return prims.size() / 4; }
 };
@@ -1003,7 +1005,19 @@ class WideBuilder {
         if (t.has_brackets || t.ents.empty() || t.ents[0].w[7] != ENT_BOX) return false;
         out = Wide();
         out.nodes.assign(WIDE_NODE_WORDS, 0u);
-        if (!node(0, 0, 1)) return false;
+        // Primitives that stand right behind the root without boxes (Builder: units no ray can miss) are not part of the
+        // tree: every walk tests them first, and the root node is the root of what follows them.
+        uint32_t top = 0;
+        const uint32_t n = (uint32_t)t.ents.size();
+        if (n > 2 && t.ents[1].w[7] != ENT_BOX) {
+            uint32_t p = 1;
+            while (p < n && t.ents[p].w[7] != ENT_BOX && (t.ents[p].w[7] & 15u) <= ENT_TRI) p++;
+            if (p - 1 > 16u || p >= n || t.ents[p].w[7] != ENT_BOX || t.ents[p].w[6] != t.ents[0].w[6]) return false;
+            for (uint32_t q = 1; q < p; q++) put_prim(q);
+            out.n_first = p - 1;
+            top = p;
+        }
+        if (!node(0, top, 1)) return false;
         return out.n_nodes() < (1u << 23) && out.n_slots() < (1u << 28);
     }
 

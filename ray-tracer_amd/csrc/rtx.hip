@@ -305,9 +305,7 @@ static void build_planar(const rtx_scene_desc_t& desc, std::vector<float4>& plan
     }
 }
 
-// Builds the traversal arrays of a scene.  A fast array that will be walked in its threaded form (small scenes: from LDS)
-// drops the boxes that cannot cull (rtx_accel::Builder::never_culls); one that turns out to need half-precision boxes and
-// with them the wide form, which is made from a strict binary tree of boxes, is built again without that.
+// Builds the traversal arrays of a scene: the choices that depend on the form the fast array will be walked in.
 static int build_arrays(const rtx_scene_desc_t& d, rtx_accel::Threaded& strict, rtx_accel::Threaded& fast, rtx_accel::Threaded& indexed, float& range,
                         std::string& err) {
     const Knobs& K = knobs();
@@ -315,19 +313,12 @@ static int build_arrays(const rtx_scene_desc_t& d, rtx_accel::Threaded& strict, 
     bool brackets = false;  // (a scene with Translate / RotateY / ConstantMedium keeps the threaded form whatever its size)
     for (uint32_t i = 0; i < d.n_objects; i++) brackets = brackets || d.objects[i].kind != RTX_OBJ_LIST;
     const bool threaded = estimate <= K.lds_ents_max || brackets;  // (what is walked in the threaded form; else the wide form, most likely)
-    const bool drop = K.drop_unculling != 0u && threaded;
+    const bool drop = K.drop_unculling != 0u;
     // In a threaded array a quad or triangle test costs about five box steps, and the builder prices it so (leaves of
     // several of them rarely pay); the wide form fetches the primitives of a leaf in one go and keeps the plain price.
     const uint32_t max_leaf = 4u;
     const float planar_cost = threaded ? 5.0f : 1.0f;
     int rc = rtx_accel::build(d, strict, fast, indexed, range, err, drop, max_leaf, planar_cost);
-    if (rc == RTX_OK && indexed.has_bare && !indexed.has_brackets &&
-        (rtx_accel::packed_slots(indexed, false) * 16 > K.lds_ents_max || env_flag("RTX_PACKED_HALF", false))) {
-        strict = rtx_accel::Threaded();
-        fast = rtx_accel::Threaded();
-        indexed = rtx_accel::Threaded();
-        rc = rtx_accel::build(d, strict, fast, indexed, range, err, false, 4u, 1.0f);
-    }
     return rc;
 }
 
@@ -534,6 +525,7 @@ static int scene_create_impl(const rtx_scene_desc_t* d, rtx_scene* s) {
                 if ((rc = upload(dc, p4, &dc->dev.wprims)) != RTX_OK) return rc;
                 if ((rc = upload(dc, w.rank, &dc->dev.wrank)) != RTX_OK) return rc;
                 dc->dev.w_levels = s->w_levels = w.levels;
+                dc->dev.w_first = w.n_first;
                 s->w_nodes = (uint32_t)w.n_nodes();
                 s->w_slots = (uint32_t)w.n_slots();
                 s->wide = true;
@@ -826,6 +818,14 @@ __global__ __launch_bounds__(256) void trace_wide_kernel(DevScene S, const rtx_r
     best.ent = NO_HIT;
     uint32_t stack[rtx_accel::WIDE_MAX_LEVELS];
     uint32_t sp = 0, group = 0, node = 0;
+    for (uint32_t k = 0; k < S.w_first; k++) {  // the primitives that stand outside the tree: every walk tests them first
+        const uint32_t o = k * 5u * PK_SLOT;
+        const auto slot_at = [&](int q) { return prims.at(o + (uint32_t)q * PK_SLOT); };
+        if (RENDER)
+            pk_render_prim<false>(slot_at(0), slot_at(1), slot_at, o, r, rc, tmin, best, rank);
+        else
+            pk_prim_test<false>(slot_at(0), slot_at(1), slot_at, o, r, rc, tmin, best, rank);
+    }
     for (;;) {
         const uint4* __restrict__ nd = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.wnodes) + (size_t)node * WIDE_NODE_BYTES);
         uint32_t next, g, tbase, tmask, n_children;
@@ -1191,6 +1191,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
     if (!WIDE) {
         RTX_LOAD_STATE(start_off, root_st);
         root_st = __builtin_amdgcn_readfirstlane(root_st);
+    } else if (P.S.w_first != 0u) {
+        root_st = PK_PRIM;  // a wide walk begins at the primitives that stand outside the tree, as if a node had handed them out
     }
 #define RTX_BEGIN_WALK()                 \
     do {                                 \
@@ -1209,7 +1211,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, XF ? (TEX ? 4 : (NOFRAMES ? RTX_FRAM
             w_node = 0u;                 \
             w_group = 0u;                \
             w_sp = 0u;                   \
-            w_tmask = 0u;                \
+            w_tbase = 0u;                \
+            w_tmask = (1u << P.S.w_first) - 1u; \
         }                                \
     } while (0)
 

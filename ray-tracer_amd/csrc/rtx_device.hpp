@@ -59,6 +59,7 @@ struct DevScene {
     const uint4* wprims;       // 5 x uint4 per primitive
     const uint32_t* wrank;     // per slot of wprims: tie-break rank of the primitive whose record starts there
     uint32_t w_levels;         // nodes on the longest path from the root = groups a walk can have pending + 1
+    uint32_t w_first;          // the first w_first records of wprims stand outside the tree: every walk tests them, then visits the root
     // Scenes with a ConstantMedium inside another one's boundary: where a walk parks the boundary-query state of the
     // enclosing media (layout: MedStack), null otherwise.  One record set per lane of a launch: launches over one
     // scene copy that overlap in time would share it.
