@@ -558,3 +558,36 @@ def test_wide_array_walks_to_the_oracle_hits(render, oracle, scenes, name, seed,
     with pytest.raises(render.RtxError) as e:
         render.Scene(bvh2, upload=False).wide_dump()
     assert e.value.code == render.RTX_ERR_UNSUPPORTED
+
+
+def test_fast_builder_structure_choices(render, scenes):
+    """Three choices of the fast builder that only change how many tests a walk makes (the walks above reach the oracle's
+    hits on the arrays as built): a unit no ray of the scene can miss -- the ground sphere whose padded box reaches over
+    everything, a medium that fills the scene -- stands right behind the root without a box of its own; a quad or
+    triangle test is priced at several box steps, so the scenes of quads get one primitive per leaf; and the packed
+    array of an LDS-sized scene holds entries of both 16-byte parities (a pad slot behind every eighth sphere)."""
+    def kinds(name, **kw):
+        cfg, bvh = scenes.make(name, seed=1, **kw)
+        ents, _ = render.Scene(bvh, upload=False).traversal_dump(render.TRAVERSAL_FAST, view=np.asarray(cfg.lookfrom, dtype=F))
+        return ents, [("box" if w == 0 else int(w) & 15) for w in ents[:, 7]]
+
+    ents, k = kinds("bouncing-spheres")
+    assert k[0] == "box" and k[1] == 1 and k[2] == "box"  # root, the ground sphere bare, the tree of the others
+    assert ents[2, 6] == ents[0, 6]  # ... which ends where the root ends
+    assert ents.view(F)[1, 6] == 1000.0
+    ents, k = kinds("final-scene")
+    assert k[:5] == ["box", 6, 1, 7, "box"] and ents[1, 4] == 1  # root, the fog: begin (boundary = one sphere), sphere, end
+    for name in ("cornell-box", "cornell-smoke", "quads"):
+        ents, k = kinds(name)
+        prim = np.array([x != "box" and (x & 7) in (2, 3) for x in k])
+        runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], prim.astype(int), [0]])))).tolist()[::2]  # lengths of runs of planar entries
+        assert max(runs) == 1, (name, runs)
+    cfg, bvh = scenes.make("bouncing-spheres", seed=1)
+    slots, _ = render.Scene(bvh, upload=False).traversal_dump(render.TRAVERSAL_FAST_FUSED, view=np.asarray(cfg.lookfrom, dtype=F))
+    starts, i = [], 0
+    while int(slots[i, 3]) != ENT_END:
+        tag = int(slots[i, 3])
+        starts.append(i)
+        i += 2 if tag < PK_PRIM else (2 + ((tag >> 27) & 1) if (tag >> 28) == 1 else 5)
+    odd = np.mean(np.array(starts) % 2 == 1)
+    assert 0.3 < odd < 0.7, odd  # entries start at even and at odd slots alike
