@@ -479,6 +479,11 @@ class Builder {
             coord_range_seen = std::fmax(coord_range_seen, u.box.max_abs());
             pad_box(u.box, coord_range);
         }
+        // The whole boundary of a medium is one primitive: the box it would get is the box the medium itself stands under
+        // (bounds_of: a medium's box is its boundary's), which a walk has passed when it arrives here.
+        if (units.size() == 1 && is_prim(units[0].ref) && units[0].chain == NONE && med_depth > 0 && !out.ents.empty() && out.ents.back().w[7] != ENT_BOX &&
+            (out.ents.back().w[7] & 15u) == ENT_MED_BEGIN)
+            return emit_unit_fast(out, units[0], false, enclosing_xf, xf_depth, med_depth);
         // Units whose box no ray of the scene can miss (never_culls: a ground sphere whose padded box reaches over
         // everything, a medium that fills the scene) are kept out of the tree: inside it they would stretch every box on
         // the way down to them to their own size, and none of those boxes could cull either.  They stand right behind the
