@@ -484,6 +484,9 @@ class Builder {
         if (units.size() == 1 && is_prim(units[0].ref) && units[0].chain == NONE && med_depth > 0 && !out.ents.empty() && out.ents.back().w[7] != ENT_BOX &&
             (out.ents.back().w[7] & 15u) == ENT_MED_BEGIN)
             return emit_unit_fast(out, units[0], false, enclosing_xf, xf_depth, med_depth);
+        // ... and for a boundary of several units the same holds for the box around all of them: its two halves stand
+        // between the medium's begin and end without it
+        skip_box_once = units.size() > 1 && med_depth > 0 && !out.ents.empty() && out.ents.back().w[7] != ENT_BOX && (out.ents.back().w[7] & 15u) == ENT_MED_BEGIN;
         // Units whose box no ray of the scene can miss (never_culls: a ground sphere whose padded box reaches over
         // everything, a medium that fills the scene) are kept out of the tree: inside it they would stretch every box on
         // the way down to them to their own size, and none of those boxes could cull either.  They stand right behind the
@@ -552,6 +555,7 @@ class Builder {
     // other ray).  Top-level frame only, never the root (whose test the render skips by itself when the camera
     // is inside).  The wide form takes the primitives that stand right behind the root as a list of its own (Wide::n_first).
     bool drop_unculling = false;
+    bool skip_box_once = false;  // the next call of sah() emits its children without the box around them (see emit_fast_subtree)
     Box3 scene_tight;          // tight bounds of everything (world frame)
     bool never_culls(const Box3& b) const {
         for (int a = 0; a < 3; a++)
@@ -578,12 +582,16 @@ class Builder {
             out.has_bare = true;
             return emit_unit_fast(out, units[begin], false, enclosing_xf, xf_depth, med_depth);
         }
+        const bool no_box = skip_box_once && n > 1;
+        skip_box_once = false;
         const uint32_t at = (uint32_t)out.ents.size();
-        const float b6[6] = {bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1], bb.lo[2], bb.hi[2]};
-        out.ents.push_back(box_entry(b6, 0));
-        out.rank.push_back(0);
-        out.mat.push_back(NONE);
-        out.n_boxes++;
+        if (!no_box) {
+            const float b6[6] = {bb.lo[0], bb.hi[0], bb.lo[1], bb.hi[1], bb.lo[2], bb.hi[2]};
+            out.ents.push_back(box_entry(b6, 0));
+            out.rank.push_back(0);
+            out.mat.push_back(NONE);
+            out.n_boxes++;
+        }
 
         int best_axis = -1, best_bin = -1;
         float best_cost = INF;
@@ -652,9 +660,10 @@ class Builder {
             const uint32_t right_at = (uint32_t)out.ents.size();
             ok = ok && sah(out, units, mid, end, enclosing_xf, xf_depth, med_depth);
             // (children that may be visited in either order: both must be boxes, whose links say where they end)
-            if (ok && out.ents[at + 1].w[7] == ENT_BOX && out.ents[at + 1].w[6] == right_at && right_at < out.ents.size() && out.ents[right_at].w[7] == ENT_BOX) out.inner.push_back(at);
+            if (!no_box && ok && out.ents[at + 1].w[7] == ENT_BOX && out.ents[at + 1].w[6] == right_at && right_at < out.ents.size() && out.ents[right_at].w[7] == ENT_BOX)
+                out.inner.push_back(at);
         }
-        out.ents[at].w[6] = (uint32_t)out.ents.size();
+        if (!no_box) out.ents[at].w[6] = (uint32_t)out.ents.size();
         return ok;
     }
 };
